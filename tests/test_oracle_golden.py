@@ -1,0 +1,77 @@
+"""CPU: the oracle restatement must reproduce every golden vector produced by the real reference
+(``tests/golden/make_golden.py``) bit for bit -- this is what pins the oracle."""
+
+import numpy as np
+import pytest
+
+from oracle.draws import InjectedDraws, philox4x32
+from oracle.qlearn_oracle import OracleQLearning
+
+from helpers import GOLDEN, TRACE_CASES, dense_from_sparse, run_oracle_trace
+from golden.make_golden_cases import LEARN_CASES, SELECT_CASES
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    kat = [
+        ((0, 0, 0, 0), (0, 0), "6627e8d5 e169c58d bc57ac4c 9b00dbd8"),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, "408f276d 41c83b0e a20bc7c6 6d5451fd"),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+         "d16cfe09 94fdcceb 5001e420 24126ea1"),
+    ]
+    for ctr, key, want in kat:
+        got = " ".join(f"{int(x):08x}" for x in philox4x32(*ctr, *key))
+        assert got == want
+
+
+@pytest.mark.parametrize("k", range(len(SELECT_CASES)))
+def test_select_matches_reference(k):
+    g = np.load(GOLDEN / "select.npz")
+    method = SELECT_CASES[k][0]
+    S, A, n, masked, det, seed = (int(v) for v in g[f"c{k}_meta"])
+    eps, step = float(g[f"c{k}_eps"][0]), int(g[f"c{k}_step"][0])
+    algo = OracleQLearning(S, A, 0.9, dtype=g[f"c{k}_q"].dtype)
+    algo.q_table = g[f"c{k}_q"].copy()
+    algo._rng = algo._np_rng = shim = InjectedDraws(seed)
+    masks = g[f"c{k}_masks"].astype(np.int32) if masked else None
+    shim.begin(step, n, eps, deterministic=bool(det))
+    fn = getattr(algo, method)
+    if method == "choose_actions_vec":
+        acts = fn(g[f"c{k}_states"], eps, deterministic=bool(det))
+    elif method == "choose_masked_actions_vec":
+        acts = fn(g[f"c{k}_states"], masks, eps, deterministic=bool(det))
+    else:
+        acts = fn(g[f"c{k}_states"], eps, deterministic=bool(det), action_masks=masks)
+    assert np.array_equal(acts, g[f"c{k}_actions"])
+
+
+@pytest.mark.parametrize("k", range(len(LEARN_CASES)))
+@pytest.mark.parametrize("fn", ["learn", "learn_vec"])
+def test_learn_matches_reference(k, fn):
+    g = np.load(GOLDEN / "learn.npz")
+    S, A, n, masked = (int(v) for v in g[f"c{k}_meta"])
+    lr, gamma = (float(v) for v in g[f"c{k}_hyper"])
+    algo = OracleQLearning(S, A, gamma, dtype=g[f"c{k}_q0"].dtype)
+    algo.q_table = g[f"c{k}_q0"].copy()
+    masks = g[f"c{k}_masks"].astype(np.int32) if masked else None
+    getattr(algo, fn)(g[f"c{k}_states"], g[f"c{k}_actions"], g[f"c{k}_rewards"],
+                      g[f"c{k}_next_states"], g[f"c{k}_terminated"], lr, masks)
+    want = g[f"c{k}_q_{fn}"]
+    assert algo.q_table.dtype == want.dtype
+    assert np.array_equal(algo.q_table, want)  # bit-exact
+
+
+@pytest.mark.parametrize("name", list(TRACE_CASES))
+def test_closed_loop_trace_matches_reference(name):
+    g = np.load(GOLDEN / "traces.npz")
+    spec, steps, dt, sched, mode = TRACE_CASES[name]
+    got = run_oracle_trace(spec, steps, dt, sched, mode)
+    assert np.array_equal(got["actions"], g[f"{name}/actions"])
+    assert np.array_equal(got["eps"], g[f"{name}/eps"])
+    assert np.array_equal(got["lr"], g[f"{name}/lr"])
+    want_q = dense_from_sparse(g[f"{name}/q_idx"], g[f"{name}/q_val"], got["q"].shape, got["q"].dtype)
+    assert np.array_equal(got["q"], want_q)
+    assert np.array_equal(got["history"], g[f"{name}/history"])
+    assert np.array_equal(got["final_obs"], g[f"{name}/final_obs"])
+    assert np.array_equal(got["agent_rewards"], g[f"{name}/agent_rewards"])
+    assert np.array_equal(got["final_sched"], g[f"{name}/final_sched"])
