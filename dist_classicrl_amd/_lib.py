@@ -1,0 +1,148 @@
+"""ctypes binding of ``libqlearn_engine.so`` (C ABI: ``include/qlearn_engine.h``).
+
+There is deliberately no CPU fallback: if the HIP library is missing, or no MI355X is visible,
+every compute entry point raises.  Building the library: ``python __graft_entry__.py`` or
+``dist_classicrl_amd/csrc/build.sh``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libqlearn_engine.so"
+
+QE_F32, QE_F64 = 0, 1
+LEARN_ITER, LEARN_VEC = 0, 1
+ENV_HASH, ENV_GRID, ENV_BANDIT = 0, 1, 2
+
+ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INDEX = -1, -2, -3, -4, -5
+
+
+class EngineError(RuntimeError):
+    """The HIP engine reported a failure that has no closer Python equivalent."""
+
+
+class EnvParams(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("masked", C.c_int32),
+        ("seed", C.c_uint32),
+        ("p_term_256", C.c_int32),
+        ("side", C.c_int32),
+        ("episode_len", C.c_int32),
+        ("agent_offset", C.c_uint32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class RolloutStats(C.Structure):
+    _fields_ = [
+        ("kernel_ms", C.c_double),
+        ("launches", C.c_int64),
+        ("episodes", C.c_int64),
+        ("involved", C.c_int64),
+        ("episodes_dropped", C.c_int64),
+    ]
+
+
+_P = C.c_void_p
+_I32P = C.POINTER(C.c_int32)
+_U32P = C.POINTER(C.c_uint32)
+_U8P = C.POINTER(C.c_uint8)
+_F32P = C.POINTER(C.c_float)
+_F64P = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); must list every symbol include/qlearn_engine.h declares
+PROTOTYPES = {
+    "qe_abi_version": (C.c_int, []),
+    "qe_last_error": (C.c_char_p, []),
+    "qe_create": (C.c_int, [C.POINTER(_P), C.c_int64, C.c_int32, C.c_double, C.c_uint64, C.c_int32, C.c_int32]),
+    "qe_destroy": (C.c_int, [_P]),
+    "qe_synchronize": (C.c_int, [_P]),
+    "qe_set_stream": (C.c_int, [_P, _P]),
+    "qe_table_upload": (C.c_int, [_P, _P, C.c_int32]),
+    "qe_table_download": (C.c_int, [_P, _P, C.c_int32]),
+    "qe_table_cells": (C.c_int, [_P, _I32P, _I32P, C.c_int64, _F64P, C.c_int32]),
+    "qe_table_dev": (_P, [_P]),
+    "qe_table_row_stride": (C.c_int64, [_P]),
+    "qe_set_step_counter": (C.c_int, [_P, C.c_uint64]),
+    "qe_get_step_counter": (C.c_uint64, [_P]),
+    "qe_set_agent_offset": (C.c_int, [_P, C.c_uint32]),
+    "qe_choose_actions": (C.c_int, [_P, _I32P, C.c_int64, _U8P, C.c_double, C.c_int32, _I32P]),
+    "qe_learn": (C.c_int, [_P, _I32P, _I32P, _F32P, _I32P, _U8P, C.c_int64, C.c_double, _U8P, C.c_int32]),
+    "qe_env_create": (C.c_int, [C.POINTER(_P), _P, C.c_int64, C.POINTER(EnvParams)]),
+    "qe_env_destroy": (C.c_int, [_P]),
+    "qe_env_reset": (C.c_int, [_P, C.c_int32, C.c_uint32]),
+    "qe_env_observe": (C.c_int, [_P, _I32P, _U8P, _F32P]),
+    "qe_env_restore": (C.c_int, [_P, _I32P, _U32P, _F32P]),
+    "qe_env_aux": (C.c_int, [_P, _U32P]),
+    "qe_env_step": (C.c_int, [_P, _I32P, _I32P, _F32P, _U8P, _U8P]),
+    "qe_rollout": (C.c_int, [_P, _P, C.c_int64, _F64P, _F64P, C.c_int32, _I32P, C.POINTER(RolloutStats)]),
+    "qe_evaluate": (C.c_int, [_P, _P, C.c_int64, C.POINTER(RolloutStats)]),
+    "qe_episode_log": (C.c_int64, [_P, C.c_int64, _I32P, _I32P, _F32P]),
+    "qe_delta_log_attach": (C.c_int, [_P, _P, C.c_int64]),
+    "qe_delta_log_count": (C.c_int64, [_P]),
+    "qe_delta_log_reset": (C.c_int, [_P]),
+    "qe_delta_apply_dev": (C.c_int, [_P, _P, C.c_int64]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises ``ImportError`` with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        msg = (
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or "
+            "dist_classicrl_amd/csrc/build.sh). The engine has no CPU fallback."
+        )
+        raise ImportError(msg)
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
+        fn.restype = res
+        fn.argtypes = args
+    if lib.qe_abi_version() != 1:
+        msg = f"ABI version mismatch: library {lib.qe_abi_version()}, binding 1"
+        raise ImportError(msg)
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Translate a negative ``qe_status`` into the exception the reference would raise."""
+    if rc >= 0:
+        return
+    text = load().qe_last_error().decode(errors="replace")
+    if rc == ERR_INDEX:
+        raise IndexError(text)
+    if rc == ERR_INVALID:
+        raise ValueError(text)
+    if rc == ERR_OOM:
+        raise MemoryError(text)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(text)
+    raise EngineError(text)
+
+
+def ptr(arr, ctype):
+    """Typed pointer to a C-contiguous NumPy array (``None`` -> NULL)."""
+    if arr is None:
+        return None
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def as_i32(x):
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+def as_u8_flags(x):
+    """Truthiness -> one byte per element (the reference treats any non-zero mask entry as valid)."""
+    x = np.asarray(x)
+    return np.ascontiguousarray(x != 0, dtype=np.uint8)

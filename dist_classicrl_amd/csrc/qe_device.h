@@ -1,0 +1,228 @@
+// qe_device.h -- device primitives of the gfx950 Q-learning engine: counter-based draws, the
+// lane-group view of a Q-table row, arg-max/tie selection, TD arithmetic.
+//
+// Row view: a row of `A` Q-values (stride `ld`, multiple of 4) is spread over a group of L
+// consecutive lanes (L = power of two, 1..64, L*4 >= ld); lane `sub` holds columns 4*sub..4*sub+3
+// from one 16-byte (fp32) / two 16-byte (fp64) loads.  A 64-wide wavefront therefore handles 64/L
+// agents; reductions stay inside the group (`__shfl_*` with width L), no LDS round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qe {
+
+constexpr uint32_t STREAM_POLICY = 0;
+constexpr uint32_t STREAM_ENV = 1;
+
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+// Philox4x32-10 (Salmon et al. SC'11); same constants as oracle/draws.py.
+__host__ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                     uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 fmix32
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct Row4 {
+    T v[4];
+};
+
+template <typename T>
+__device__ __forceinline__ T neg_inf() {
+    return -__builtin_huge_val();
+}
+template <>
+__device__ __forceinline__ float neg_inf<float>() {
+    return -__builtin_huge_valf();
+}
+
+// Plain (cached) row load: used where no other workgroup writes the row inside this launch.
+__device__ __forceinline__ Row4<float> load_row4(const float* q, int64_t row, int ld, int sub) {
+    Row4<float> r;
+    const int c = 4 * sub;
+    if (c < ld) {
+        const float4 f = *reinterpret_cast<const float4*>(q + row * ld + c);
+        r.v[0] = f.x; r.v[1] = f.y; r.v[2] = f.z; r.v[3] = f.w;
+    } else {
+        r.v[0] = r.v[1] = r.v[2] = r.v[3] = neg_inf<float>();
+    }
+    return r;
+}
+__device__ __forceinline__ Row4<double> load_row4(const double* q, int64_t row, int ld, int sub) {
+    Row4<double> r;
+    const int c = 4 * sub;
+    if (c < ld) {
+        const double2* p = reinterpret_cast<const double2*>(q + row * ld + c);
+        const double2 a = p[0], b = p[1];
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+    } else {
+        r.v[0] = r.v[1] = r.v[2] = r.v[3] = neg_inf<double>();
+    }
+    return r;
+}
+
+// Coherent element access (agent scope, bypasses the CU's L1): used by the ordered path, where
+// other waves of the same launch have written the table.
+template <typename T>
+__device__ __forceinline__ T load_live(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void store_live(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ Row4<T> load_row4_live(const T* q, int64_t row, int ld, int sub) {
+    Row4<T> r;
+    const int c = 4 * sub;
+    if (c < ld) {
+        const T* p = q + row * ld + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.v[j] = load_live(p + j);
+    } else {
+        r.v[0] = r.v[1] = r.v[2] = r.v[3] = neg_inf<T>();
+    }
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ T group_max(T v, int L) {
+    for (int off = L >> 1; off > 0; off >>= 1) {
+        const T o = __shfl_xor(v, off, L);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int group_max_int(int v, int L) {
+    for (int off = L >> 1; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off, L);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// max over the valid columns of this lane's 4 elements, reduced over the group (-inf if none).
+template <typename T>
+__device__ __forceinline__ T row_max_valid(const Row4<T>& row, uint32_t valid4, int L) {
+    T m = neg_inf<T>();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((valid4 >> j) & 1u) m = row.v[j] > m ? row.v[j] : m;
+    return group_max(m, L);
+}
+
+// columns < A of this lane, as a 4-bit field
+__device__ __forceinline__ uint32_t in_range4(int sub, int A) {
+    const int rem = A - 4 * sub;
+    return rem >= 4 ? 0xFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+}
+
+// Epsilon-greedy pick (all reference choose_action* variants share this distribution,
+// q_learning_optimal.py:263-642): explore -> k-th valid action, k = mulhi(x1, n_valid);
+// greedy -> k-th action tied at the valid maximum, k = mulhi(x2, n_ties).  Returns -1 when no
+// action is selectable.  *picked_q receives Q[s, action] as held in `row`.
+template <typename T>
+__device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4, int sub, int L,
+                                             bool explore, uint32_t x1, uint32_t x2, T* picked_q) {
+    const T m = row_max_valid(row, valid4, L);
+    uint32_t f = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool ok = ((valid4 >> j) & 1u) && (explore || row.v[j] == m);
+        f |= (ok ? 1u : 0u) << j;
+    }
+    const int cnt = __popc(f);
+    int incl = cnt;
+    for (int off = 1; off < L; off <<= 1) {
+        const int t = __shfl_up(incl, off, L);
+        if (sub >= off) incl += t;
+    }
+    const int total = __shfl(incl, L - 1, L);
+    int act = -1;
+    if (total > 0) {
+        const int k = (int)mulhi32(explore ? x1 : x2, (uint32_t)total);
+        const int excl = incl - cnt;
+        if (k >= excl && k < incl) {
+            uint32_t g = f;
+            for (int r = k - excl; r > 0; --r) g &= g - 1u;
+            act = 4 * sub + (__ffs(g) - 1);
+        }
+    }
+    act = group_max_int(act, L);
+    const int jj = act & 3;
+    const T mine = jj == 0 ? row.v[0] : (jj == 1 ? row.v[1] : (jj == 2 ? row.v[2] : row.v[3]));
+    *picked_q = __shfl(mine, act < 0 ? 0 : (act >> 2), L);
+    return act;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TD arithmetic.  Compiled with -ffp-contract=off: every operation rounds exactly once, in the
+// order the reference performs it, so fp32 results equal the reference run on a float32 table and
+// fp64 results equal the reference's default float64 table, bit for bit.
+//
+// ITER = single_learn (q_learning_optimal.py:728-768) under NEP-50 promotion:
+//        t = g*m ; y = r + t ; d = y - q ; u = lr*d ; q' = q + u          (all in the table dtype)
+// VEC  = _learn_vec (:819-891): on a float32 table `(1 - terminated)` is int64, which promotes the
+//        target to float64; the increment is rounded to float32 once by np.add.at.
+struct Hyper {
+    double gamma, lr;
+    float gamma32, lr32;
+};
+
+template <typename T>
+struct Td;
+
+template <>
+struct Td<float> {
+    static __device__ __forceinline__ float delta(float q, float r, float m, bool term,
+                                                  const Hyper& h, int mode) {
+        if (mode == 0) {
+            const float t = term ? 0.0f : h.gamma32 * m;
+            const float y = r + t;
+            const float d = y - q;
+            return h.lr32 * d;
+        }
+        const float t32 = h.gamma32 * m;
+        const double t = term ? 0.0 : (double)t32;
+        const double y = (double)r + t;
+        const double d = y - (double)q;
+        return (float)(h.lr * d);
+    }
+};
+
+template <>
+struct Td<double> {
+    static __device__ __forceinline__ double delta(double q, float r, double m, bool term,
+                                                   const Hyper& h, int /*mode*/) {
+        const double t = term ? 0.0 : h.gamma * m;
+        const double y = (double)r + t;
+        const double d = y - q;
+        return h.lr * d;
+    }
+};
+
+}  // namespace qe

@@ -1,0 +1,734 @@
+// qe_engine.hip -- host side of libqlearn_engine.so: owns the HBM-resident Q-table and agent
+// state, launches the gfx950 kernels of qe_kernels.h, exports the C ABI of include/qlearn_engine.h.
+#include "../../include/qlearn_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qe_kernels.h"
+
+using namespace qe;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(_e == hipErrorOutOfMemory ? QE_ERR_OOM : QE_ERR_NO_DEVICE,           \
+                        "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e),    \
+                        __FILE__, __LINE__, #expr);                                          \
+    } while (0)
+
+template <typename U>
+struct DevBuf {
+    U* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(n, (size_t)256);
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(U));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+int lanes_per_row(int ld) {  // smallest power of two L with 4*L >= ld
+    int L = 1;
+    while (4 * L < ld) L <<= 1;
+    return L;
+}
+
+}  // namespace
+
+struct qe_engine {
+    int device = 0;
+    int dtype = QE_F32;
+    int64_t S = 0;
+    int32_t A = 0, ld = 0, L = 1, lshift = 0;
+    double gamma = 0.97;
+    uint64_t seed = 0, step_ctr = 0;
+    uint32_t agent_offset = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    void* q = nullptr;
+    uint32_t* stamps = nullptr;
+    Ctrl* ctrl = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // schedules
+    DevBuf<unsigned long long> thr;
+    DevBuf<double> lr;
+    // batch-API scratch (qe_choose_actions / qe_learn / qe_table_cells)
+    DevBuf<int32_t> b_s, b_a, b_n, b_out, b_list;
+    DevBuf<float> b_r, b_acc;
+    DevBuf<uint8_t> b_term, b_pred;
+    DevBuf<uint32_t> b_aux, b_mask, b_bitmap;
+    DevBuf<double> b_vals;
+    // episode log
+    DevBuf<unsigned long long> ep_key;
+    DevBuf<float> ep_ret;
+    long long ep_cap = 1 << 22;
+    std::vector<std::pair<unsigned long long, float>> ep_host;
+    // delta log (caller-owned buffer)
+    DeltaEntry* dlog = nullptr;
+    long long dlog_cap = 0, dlog_count = 0;
+    DevBuf<int32_t> trace;
+    size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
+};
+
+struct qe_env {
+    qe_engine* e = nullptr;
+    qe_env_params p{};
+    int64_t N = 0;
+    DevBuf<int32_t> s, a, n, list;
+    DevBuf<float> r, acc;
+    DevBuf<uint8_t> term, pred, masks;
+    DevBuf<uint32_t> aux, bitmap;
+};
+
+namespace {
+
+EnvCtx make_envctx(const qe_engine* e, const qe_env_params* p, const uint32_t* maskbits, int masked) {
+    EnvCtx ev{};
+    ev.S = e->S;
+    ev.A = e->A;
+    ev.n_words = (e->A + 31) / 32;
+    ev.maskbits = maskbits;
+    if (p) {
+        ev.kind = p->kind; ev.masked = p->masked; ev.seed = p->seed; ev.p_term_256 = p->p_term_256;
+        ev.side = p->side; ev.episode_len = p->episode_len; ev.agent_offset = p->agent_offset;
+    } else {
+        ev.kind = -1; ev.masked = masked;
+    }
+    return ev;
+}
+
+template <typename T>
+Ctx<T> base_ctx(qe_engine* e, int64_t N) {
+    Ctx<T> c{};
+    c.q = (T*)e->q; c.S = e->S; c.A = e->A; c.ld = e->ld; c.L = e->L; c.lshift = e->lshift;
+    c.N = N; c.stamps = e->stamps; c.ctrl = e->ctrl;
+    c.thr = e->thr.p; c.lr = e->lr.p;
+    c.seed_lo = (uint32_t)e->seed; c.seed_hi = (uint32_t)(e->seed >> 32);
+    c.agent_offset = e->agent_offset; c.step0 = e->step_ctr; c.gamma = e->gamma;
+    c.ep_key = e->ep_key.p; c.ep_ret = e->ep_ret.p; c.ep_cap = e->ep_cap;
+    return c;
+}
+
+template <typename T>
+Ctx<T> env_ctx(qe_engine* e, qe_env* env) {
+    Ctx<T> c = base_ctx<T>(e, env->N);
+    c.s = env->s.p; c.a = env->a.p; c.n = env->n.p; c.r = env->r.p; c.term = env->term.p;
+    c.pred = (T*)env->pred.p; c.aux = env->aux.p; c.acc = env->acc.p;
+    c.inv_bitmap = env->bitmap.p; c.inv_list = env->list.p;
+    c.agent_offset = env->p.agent_offset;
+    return c;
+}
+
+inline unsigned grid_for(int64_t threads, int block) { return (unsigned)((threads + block - 1) / block); }
+
+unsigned long long eps_threshold(double eps) {
+    if (!(eps > 0.0)) return 0ull;
+    if (eps >= 1.0) return 1ull << 32;
+    const double v = std::ceil(eps * 4294967296.0);
+    return v >= 4294967296.0 ? (1ull << 32) : (unsigned long long)v;
+}
+
+int upload_schedules(qe_engine* e, int64_t steps, const double* eps, const double* lr) {
+    std::vector<unsigned long long> thr((size_t)steps);
+    for (int64_t t = 0; t < steps; ++t) thr[(size_t)t] = eps ? eps_threshold(eps[t]) : 0ull;
+    HIP_TRY(e->thr.ensure((size_t)steps));
+    HIP_TRY(e->lr.ensure((size_t)steps));
+    HIP_TRY(hipMemcpyAsync(e->thr.p, thr.data(), steps * sizeof(unsigned long long),
+                           hipMemcpyHostToDevice, e->stream));
+    if (lr) {
+        HIP_TRY(hipMemcpyAsync(e->lr.p, lr, steps * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(e->lr.p, 0, steps * sizeof(double), e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));  // `thr` is a host temporary
+    return QE_OK;
+}
+
+// pack n*A mask bytes into n_words uint32 per agent
+void pack_masks(const uint8_t* masks, int64_t n, int A, std::vector<uint32_t>& out) {
+    const int nw = (A + 31) / 32;
+    out.assign((size_t)n * nw, 0u);
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < A; ++j)
+            if (masks[i * A + j]) out[(size_t)i * nw + (j >> 5)] |= 1u << (j & 31);
+}
+
+template <typename T, class Env>
+int launch_step(qe_engine* e, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow, int64_t* launches) {
+    hipLaunchKernelGGL((k_step_fast<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK),
+                       0, e->stream, c, ev, flags);
+    ++*launches;
+    if (slow) {
+        hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
+        ++*launches;
+    }
+    return QE_OK;
+}
+
+
+
+template <typename T, class Env>
+int rollout_impl(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, int32_t* trace_host,
+                 qe_rollout_stats* st) {
+    Ctx<T> c = env_ctx<T>(e, env);
+    c.mode = mode;
+    const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
+    if (trace_host) {
+        HIP_TRY(e->trace.ensure((size_t)(steps * env->N)));
+        c.trace = e->trace.p;
+    }
+    if (e->dlog && learn) {
+        c.dlog = e->dlog; c.dlog_base = e->dlog_count; c.dlog_cap = e->dlog_cap;
+    }
+    Ctrl init{};
+    HIP_TRY(hipMemcpyAsync(e->ctrl, &init, sizeof init, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    int64_t launches = 0;
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    if (learn) {
+        const int base = FLAG_ACCOUNT;
+        launch_step<T, Env>(e, c, ev, base | FLAG_SELECT, false, &launches);  // select(0), env(0)
+        for (int64_t t = 0; t + 1 < steps; ++t)
+            launch_step<T, Env>(e, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, &launches);
+        launch_step<T, Env>(e, c, ev, base | FLAG_LEARN, true, &launches);  // learn(steps-1)
+    } else {
+        // greedy evaluation: no table writes, hence no contention and no ordered path
+        hipLaunchKernelGGL((k_eval<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK), 0,
+                           e->stream, c, ev, (long long)steps);
+        ++launches;
+    }
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    Ctrl fin{};
+    HIP_TRY(hipMemcpy(&fin, e->ctrl, sizeof fin, hipMemcpyDeviceToHost));
+    // episode log -> host, sorted by (step, agent) = append order of base_runtime.py:218-221
+    const long long got = std::min<long long>((long long)fin.ep_count, e->ep_cap);
+    std::vector<unsigned long long> keys((size_t)got);
+    std::vector<float> rets((size_t)got);
+    if (got) {
+        HIP_TRY(hipMemcpy(keys.data(), e->ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rets.data(), e->ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    e->ep_host.resize((size_t)got);
+    for (long long k = 0; k < got; ++k) e->ep_host[(size_t)k] = {keys[(size_t)k], rets[(size_t)k]};
+    std::sort(e->ep_host.begin(), e->ep_host.end(),
+              [](const auto& x, const auto& y) { return x.first < y.first; });
+    if (trace_host)
+        HIP_TRY(hipMemcpy(trace_host, e->trace.p, steps * env->N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (c.dlog) e->dlog_count = std::min<long long>(e->dlog_count + steps * env->N, e->dlog_cap);
+    e->step_ctr += (uint64_t)steps;
+    if (st) {
+        st->kernel_ms = ms; st->launches = launches; st->episodes = (int64_t)fin.ep_count;
+        st->involved = (int64_t)fin.involved_total;
+        st->episodes_dropped = (int64_t)fin.ep_count - got;
+    }
+    return QE_OK;
+}
+
+template <typename T>
+int rollout_dispatch(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, int32_t* trace,
+                     qe_rollout_stats* st) {
+    switch (env->p.kind) {
+        case QE_ENV_HASH: return rollout_impl<T, HashEnv>(e, env, steps, mode, learn, trace, st);
+        case QE_ENV_GRID: return rollout_impl<T, GridEnv>(e, env, steps, mode, learn, trace, st);
+        case QE_ENV_BANDIT: return rollout_impl<T, BanditEnv>(e, env, steps, mode, learn, trace, st);
+    }
+    return fail(QE_ERR_INVALID, "unknown env kind %d", env->p.kind);
+}
+
+template <class F>
+int by_kind(int kind, F f) {
+    switch (kind) {
+        case QE_ENV_HASH: return f(HashEnv{});
+        case QE_ENV_GRID: return f(GridEnv{});
+        case QE_ENV_BANDIT: return f(BanditEnv{});
+    }
+    return fail(QE_ERR_INVALID, "unknown env kind %d", kind);
+}
+
+int check_indices(const int32_t* v, int64_t n, int64_t bound, const char* what) {
+    for (int64_t i = 0; i < n; ++i)
+        if (v[i] < 0 || v[i] >= bound)
+            return fail(QE_ERR_INDEX, "%s[%lld] = %d is out of range [0, %lld)", what, (long long)i,
+                        (int)v[i], (long long)bound);
+    return QE_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int qe_abi_version(void) { return QE_ABI_VERSION; }
+const char* qe_last_error(void) { return g_err.c_str(); }
+
+int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed, int32_t dtype,
+              int32_t device) {
+    if (!out) return fail(QE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (S <= 0 || A <= 0) return fail(QE_ERR_INVALID, "state_size and action_size must be positive");
+    if (dtype != QE_F32 && dtype != QE_F64) return fail(QE_ERR_INVALID, "dtype must be QE_F32 or QE_F64");
+    if ((double)S * ((A + 3) / 4 * 4) >= 4294967296.0)
+        return fail(QE_ERR_UNSUPPORTED, "state_size * padded action_size must be < 2^32 cells");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(QE_ERR_NO_DEVICE, "no HIP device visible: the Q-learning engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(QE_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    qe_engine* e = new qe_engine();
+    e->device = device; e->dtype = dtype; e->S = S; e->A = A; e->ld = (A + 3) / 4 * 4;
+    e->L = lanes_per_row(e->ld);
+    if (e->L > 64) e->L = 64;  // A > 256: the wave-per-row kernels take over
+    for (e->lshift = 0; (1 << e->lshift) < e->L; ++e->lshift) {}
+    e->gamma = gamma; e->seed = seed;
+    const size_t bytes = (size_t)S * e->ld * e->esize();
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipMalloc(&e->q, bytes);
+    if (err == hipSuccess) err = hipMalloc((void**)&e->stamps, (size_t)S * 2 * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMalloc((void**)&e->ctrl, sizeof(Ctrl));
+    if (err == hipSuccess) err = hipEventCreate(&e->ev0);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev1);
+    if (err == hipSuccess) err = e->ep_key.ensure((size_t)e->ep_cap);
+    if (err == hipSuccess) err = e->ep_ret.ensure((size_t)e->ep_cap);
+    if (err == hipSuccess) err = hipMemsetAsync(e->q, 0, bytes, e->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(e->stamps, 0, (size_t)S * 2 * sizeof(uint32_t), e->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err != hipSuccess) {
+        int code = fail(err == hipErrorOutOfMemory ? QE_ERR_OOM : QE_ERR_NO_DEVICE,
+                        "engine allocation failed: %s", hipGetErrorString(err));
+        qe_destroy(e);
+        return code;
+    }
+    *out = e;
+    return QE_OK;
+}
+
+int qe_destroy(qe_engine* e) {
+    if (!e) return QE_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->q) (void)hipFree(e->q);
+    if (e->stamps) (void)hipFree(e->stamps);
+    if (e->ctrl) (void)hipFree(e->ctrl);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    e->thr.release(); e->lr.release(); e->b_s.release(); e->b_a.release(); e->b_n.release();
+    e->b_out.release(); e->b_list.release(); e->b_r.release(); e->b_acc.release(); e->b_term.release();
+    e->b_pred.release(); e->b_aux.release(); e->b_mask.release(); e->b_bitmap.release();
+    e->b_vals.release(); e->ep_key.release(); e->ep_ret.release(); e->trace.release();
+    if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return QE_OK;
+}
+
+int qe_synchronize(qe_engine* e) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QE_OK;
+}
+
+int qe_set_stream(qe_engine* e, void* s) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    e->stream = (hipStream_t)s;
+    e->own_stream = false;
+    return QE_OK;
+}
+
+// ---- table -----------------------------------------------------------------------------------
+static int table_xfer(qe_engine* e, void* host, int host_dtype, bool up) {
+    if (!host) return fail(QE_ERR_INVALID, "host buffer is NULL");
+    if (host_dtype != QE_F32 && host_dtype != QE_F64) return fail(QE_ERR_INVALID, "bad host dtype");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t hs = host_dtype == QE_F32 ? 4 : 8, ds = e->esize();
+    const size_t cells = (size_t)e->S * e->A;
+    // convert on the host into the device dtype, then a strided copy handles the row padding
+    std::vector<unsigned char> tmp;
+    void* staged = host;
+    if (hs != ds) {
+        tmp.resize(cells * ds);
+        staged = tmp.data();
+        if (up) {
+            if (ds == 4) for (size_t k = 0; k < cells; ++k) ((float*)staged)[k] = (float)((const double*)host)[k];
+            else for (size_t k = 0; k < cells; ++k) ((double*)staged)[k] = (double)((const float*)host)[k];
+        }
+    }
+    if (up) {
+        HIP_TRY(hipMemcpy2DAsync(e->q, e->ld * ds, staged, e->A * ds, e->A * ds, (size_t)e->S,
+                                 hipMemcpyHostToDevice, e->stream));
+    } else {
+        HIP_TRY(hipMemcpy2DAsync(staged, e->A * ds, e->q, e->ld * ds, e->A * ds, (size_t)e->S,
+                                 hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!up && hs != ds) {
+        if (hs == 4) for (size_t k = 0; k < cells; ++k) ((float*)host)[k] = (float)((const double*)staged)[k];
+        else for (size_t k = 0; k < cells; ++k) ((double*)host)[k] = (double)((const float*)staged)[k];
+    }
+    return QE_OK;
+}
+
+int qe_table_upload(qe_engine* e, const void* host, int32_t host_dtype) {
+    return table_xfer(e, const_cast<void*>(host), host_dtype, true);
+}
+int qe_table_download(qe_engine* e, void* host, int32_t host_dtype) {
+    return table_xfer(e, host, host_dtype, false);
+}
+
+int qe_table_cells(qe_engine* e, const int32_t* states, const int32_t* actions, int64_t n, double* vals,
+                   int32_t op) {
+    if (n == 0) return QE_OK;
+    if (!states || !actions || !vals || op < 0 || op > 2) return fail(QE_ERR_INVALID, "bad argument");
+    if (int rc = check_indices(states, n, e->S, "states")) return rc;
+    if (int rc = check_indices(actions, n, e->A, "actions")) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(e->b_s.ensure((size_t)n)); HIP_TRY(e->b_a.ensure((size_t)n)); HIP_TRY(e->b_vals.ensure((size_t)n));
+    HIP_TRY(hipMemcpyAsync(e->b_s.p, states, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_a.p, actions, n * 4, hipMemcpyHostToDevice, e->stream));
+    if (op != 0) HIP_TRY(hipMemcpyAsync(e->b_vals.p, vals, n * 8, hipMemcpyHostToDevice, e->stream));
+    const unsigned g = op == 2 ? 1u : grid_for(n, 256);
+    if (e->dtype == QE_F32)
+        hipLaunchKernelGGL(k_cells<float>, dim3(g), dim3(256), 0, e->stream, (float*)e->q, e->ld, e->b_s.p, e->b_a.p, n, e->b_vals.p, op);
+    else
+        hipLaunchKernelGGL(k_cells<double>, dim3(g), dim3(256), 0, e->stream, (double*)e->q, e->ld, e->b_s.p, e->b_a.p, n, e->b_vals.p, op);
+    if (op == 0) HIP_TRY(hipMemcpyAsync(vals, e->b_vals.p, n * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+void* qe_table_dev(qe_engine* e) { return e->q; }
+int64_t qe_table_row_stride(qe_engine* e) { return e->ld; }
+
+int qe_set_step_counter(qe_engine* e, uint64_t step) { e->step_ctr = step; return QE_OK; }
+uint64_t qe_get_step_counter(qe_engine* e) { return e->step_ctr; }
+int qe_set_agent_offset(qe_engine* e, uint32_t off) { e->agent_offset = off; return QE_OK; }
+
+// ---- selection -------------------------------------------------------------------------------
+int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint8_t* masks, double eps,
+                      int32_t deterministic, int32_t* out) {
+    if (n < 0 || (n > 0 && (!states || !out))) return fail(QE_ERR_INVALID, "bad argument");
+    if (n == 0) { e->step_ctr += 1; return QE_OK; }
+    if (int rc = check_indices(states, n, e->S, "states")) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(e->b_s.ensure((size_t)n)); HIP_TRY(e->b_out.ensure((size_t)n));
+    HIP_TRY(hipMemcpyAsync(e->b_s.p, states, n * 4, hipMemcpyHostToDevice, e->stream));
+    std::vector<uint32_t> packed;
+    if (masks) {
+        pack_masks(masks, n, e->A, packed);
+        HIP_TRY(e->b_mask.ensure(packed.size()));
+        HIP_TRY(hipMemcpyAsync(e->b_mask.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    const EnvCtx ev = make_envctx(e, nullptr, e->b_mask.p, masks ? 1 : 0);
+    const unsigned long long thr = eps_threshold(eps);
+    const bool large = e->ld > 256;
+    auto go = [&](auto tag) {
+        using T = decltype(tag);
+        Ctx<T> c = base_ctx<T>(e, n);
+        if (large)
+            hipLaunchKernelGGL(k_select_large<T>, dim3(grid_for(n * 64, FAST_BLOCK)), dim3(FAST_BLOCK), 0,
+                               e->stream, c, ev, e->b_s.p, thr, deterministic, e->b_out.p);
+        else
+            hipLaunchKernelGGL(k_select<T>, dim3(grid_for(n * e->L, FAST_BLOCK)), dim3(FAST_BLOCK), 0,
+                               e->stream, c, ev, e->b_s.p, thr, deterministic, e->b_out.p);
+    };
+    if (e->dtype == QE_F32) go(float{}); else go(double{});
+    HIP_TRY(hipMemcpyAsync(out, e->b_out.p, n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    e->step_ctr += 1;
+    return QE_OK;
+}
+
+// ---- learning --------------------------------------------------------------------------------
+int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const float* rewards,
+             const int32_t* next_states, const uint8_t* terminated, int64_t n, double lr,
+             const uint8_t* next_masks, int32_t mode) {
+    if (n == 0) return QE_OK;
+    if (n < 0 || !states || !actions || !rewards || !next_states || !terminated)
+        return fail(QE_ERR_INVALID, "bad argument");
+    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
+    if (int rc = check_indices(states, n, e->S, "states")) return rc;
+    if (int rc = check_indices(actions, n, e->A, "actions")) return rc;
+    // the sequential form never reads the next-state row of a terminated transition
+    // (q_learning_optimal.py:756-763): such entries are re-pointed at the written row.
+    std::vector<int32_t> nxt(next_states, next_states + n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (terminated[i] && mode == QE_LEARN_ITER) nxt[(size_t)i] = states[i];
+        else if (nxt[(size_t)i] < 0 || nxt[(size_t)i] >= e->S)
+            return fail(QE_ERR_INDEX, "next_states[%lld] = %d is out of range", (long long)i, (int)nxt[(size_t)i]);
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t un = (size_t)n;
+    HIP_TRY(e->b_s.ensure(un)); HIP_TRY(e->b_a.ensure(un)); HIP_TRY(e->b_n.ensure(un));
+    HIP_TRY(e->b_r.ensure(un)); HIP_TRY(e->b_term.ensure(un)); HIP_TRY(e->b_pred.ensure(un * 8));
+    HIP_TRY(e->b_aux.ensure(un)); HIP_TRY(e->b_acc.ensure(un)); HIP_TRY(e->b_list.ensure(un));
+    const size_t words = (un + 31) / 32;
+    if (words > e->b_bitmap.cap) {
+        HIP_TRY(e->b_bitmap.ensure(words));
+        HIP_TRY(hipMemsetAsync(e->b_bitmap.p, 0, e->b_bitmap.cap * 4, e->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(e->b_s.p, states, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_a.p, actions, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_n.p, nxt.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_r.p, rewards, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_term.p, terminated, n, hipMemcpyHostToDevice, e->stream));
+    std::vector<uint32_t> packed;
+    if (next_masks) {
+        pack_masks(next_masks, n, e->A, packed);
+        HIP_TRY(e->b_mask.ensure(packed.size()));
+        HIP_TRY(hipMemcpyAsync(e->b_mask.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    const unsigned long long thr0 = 0;
+    HIP_TRY(e->thr.ensure(1)); HIP_TRY(e->lr.ensure(1));
+    HIP_TRY(hipMemcpyAsync(e->thr.p, &thr0, 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->lr.p, &lr, 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
+    const EnvCtx ev = make_envctx(e, nullptr, e->b_mask.p, next_masks ? 1 : 0);
+    const bool large = e->ld > 256;
+    auto go = [&](auto tag) {
+        using T = decltype(tag);
+        Ctx<T> c = base_ctx<T>(e, n);
+        c.mode = mode;
+        c.s = e->b_s.p; c.a = e->b_a.p; c.n = e->b_n.p; c.r = e->b_r.p; c.term = e->b_term.p;
+        c.pred = (T*)e->b_pred.p; c.aux = e->b_aux.p; c.acc = e->b_acc.p;
+        c.inv_bitmap = e->b_bitmap.p; c.inv_list = e->b_list.p;
+        if (large) {
+            hipLaunchKernelGGL(k_learn_large<T>, dim3(1), dim3(64), 0, e->stream, c, ev, lr);
+            return;
+        }
+        hipLaunchKernelGGL(k_touch_batch<T>, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, c);
+        const int flags = FLAG_LEARN | FLAG_PRED_FROM_TABLE;
+        hipLaunchKernelGGL((k_step_fast<T, HostEnv>), dim3(grid_for(n * e->L, FAST_BLOCK)), dim3(FAST_BLOCK), 0, e->stream, c, ev, flags);
+        hipLaunchKernelGGL((k_step_slow<T, HostEnv>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
+    };
+    if (e->dtype == QE_F32) go(float{}); else go(double{});
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+// ---- environments ------------------------------------------------------------------------------
+int qe_env_create(qe_env** out, qe_engine* e, int64_t N, const qe_env_params* p) {
+    if (!out || !e || !p || N <= 0) return fail(QE_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    if (e->ld > 256) return fail(QE_ERR_UNSUPPORTED, "device environments support action_size <= 256");
+    switch (p->kind) {
+        case QE_ENV_HASH:
+            if (p->p_term_256 < 0 || p->p_term_256 > 256) return fail(QE_ERR_INVALID, "p_term_256 out of range");
+            break;
+        case QE_ENV_GRID:
+            if (p->side < 2 || (int64_t)p->side * p->side != e->S || e->A != 4)
+                return fail(QE_ERR_INVALID, "GridLake needs state_size == side*side and action_size == 4");
+            break;
+        case QE_ENV_BANDIT:
+            if (e->S != 1 || e->A != 2 || p->episode_len <= 0)
+                return fail(QE_ERR_INVALID, "bandit needs state_size 1, action_size 2, episode_len > 0");
+            break;
+        default: return fail(QE_ERR_INVALID, "unknown env kind %d", p->kind);
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    qe_env* env = new qe_env();
+    env->e = e; env->p = *p; env->N = N;
+    const size_t un = (size_t)N;
+    hipError_t err = env->s.ensure(un);
+    if (err == hipSuccess) err = env->a.ensure(un);
+    if (err == hipSuccess) err = env->n.ensure(un);
+    if (err == hipSuccess) err = env->list.ensure(un);
+    if (err == hipSuccess) err = env->r.ensure(un);
+    if (err == hipSuccess) err = env->acc.ensure(un);
+    if (err == hipSuccess) err = env->term.ensure(un);
+    if (err == hipSuccess) err = env->pred.ensure(un * 8);
+    if (err == hipSuccess) err = env->aux.ensure(un);
+    if (err == hipSuccess) err = env->bitmap.ensure((un + 31) / 32);
+    if (err == hipSuccess) err = hipMemsetAsync(env->bitmap.p, 0, env->bitmap.cap * 4, e->stream);
+    if (err != hipSuccess) {
+        qe_env_destroy(env);
+        return fail(QE_ERR_OOM, "env allocation failed: %s", hipGetErrorString(err));
+    }
+    *out = env;
+    return qe_env_reset(env, 0, 0);
+}
+
+int qe_env_destroy(qe_env* env) {
+    if (!env) return QE_OK;
+    (void)hipSetDevice(env->e->device);
+    (void)hipStreamSynchronize(env->e->stream);
+    env->s.release(); env->a.release(); env->n.release(); env->list.release(); env->r.release();
+    env->acc.release(); env->term.release(); env->pred.release(); env->aux.release();
+    env->bitmap.release(); env->masks.release();
+    delete env;
+    return QE_OK;
+}
+
+int qe_env_reset(qe_env* env, int32_t has_seed, uint32_t seed) {
+    qe_engine* e = env->e;
+    HIP_TRY(hipSetDevice(e->device));
+    if (has_seed) env->p.seed = seed;
+    const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
+    int rc = by_kind(env->p.kind, [&](auto tag) {
+        using Env = decltype(tag);
+        hipLaunchKernelGGL(k_env_reset<Env>, dim3(grid_for(env->N, 256)), dim3(256), 0, e->stream, ev,
+                           env->N, env->n.p, env->aux.p, env->acc.p);
+        return QE_OK;
+    });
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+int qe_env_observe(qe_env* env, int32_t* obs, uint8_t* masks, float* agent_rewards) {
+    qe_engine* e = env->e;
+    HIP_TRY(hipSetDevice(e->device));
+    if (obs) HIP_TRY(hipMemcpyAsync(obs, env->n.p, env->N * 4, hipMemcpyDeviceToHost, e->stream));
+    if (agent_rewards) HIP_TRY(hipMemcpyAsync(agent_rewards, env->acc.p, env->N * 4, hipMemcpyDeviceToHost, e->stream));
+    if (masks) {
+        const size_t bytes = (size_t)env->N * e->A;
+        HIP_TRY(env->masks.ensure(bytes));
+        const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
+        const int nsub = (e->A + 3) / 4;
+        int rc = by_kind(env->p.kind, [&](auto tag) {
+            using Env = decltype(tag);
+            hipLaunchKernelGGL(k_env_masks<Env>, dim3(grid_for(env->N * nsub, 256)), dim3(256), 0, e->stream,
+                               ev, env->N, env->n.p, env->masks.p);
+            return QE_OK;
+        });
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(masks, env->masks.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+int qe_env_restore(qe_env* env, const int32_t* obs, const uint32_t* aux, const float* agent_rewards) {
+    qe_engine* e = env->e;
+    HIP_TRY(hipSetDevice(e->device));
+    if (obs) {
+        if (int rc = check_indices(obs, env->N, e->S, "obs")) return rc;
+        HIP_TRY(hipMemcpyAsync(env->n.p, obs, env->N * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    if (aux) HIP_TRY(hipMemcpyAsync(env->aux.p, aux, env->N * 4, hipMemcpyHostToDevice, e->stream));
+    if (agent_rewards) HIP_TRY(hipMemcpyAsync(env->acc.p, agent_rewards, env->N * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QE_OK;
+}
+
+int qe_env_aux(qe_env* env, uint32_t* aux) {
+    HIP_TRY(hipSetDevice(env->e->device));
+    HIP_TRY(hipMemcpy(aux, env->aux.p, env->N * 4, hipMemcpyDeviceToHost));
+    return QE_OK;
+}
+
+int qe_env_step(qe_env* env, const int32_t* actions, int32_t* obs, float* rewards, uint8_t* terminated,
+                uint8_t* masks) {
+    qe_engine* e = env->e;
+    if (!actions) return fail(QE_ERR_INVALID, "actions is NULL");
+    if (int rc = check_indices(actions, env->N, e->A, "actions")) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(env->a.p, actions, env->N * 4, hipMemcpyHostToDevice, e->stream));
+    const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
+    int rc = by_kind(env->p.kind, [&](auto tag) {
+        using Env = decltype(tag);
+        hipLaunchKernelGGL(k_env_step<Env>, dim3(grid_for(env->N, 256)), dim3(256), 0, e->stream, ev, env->N,
+                           env->a.p, env->n.p, env->aux.p, env->r.p, env->term.p);
+        return QE_OK;
+    });
+    if (rc) return rc;
+    if (rewards) HIP_TRY(hipMemcpyAsync(rewards, env->r.p, env->N * 4, hipMemcpyDeviceToHost, e->stream));
+    if (terminated) HIP_TRY(hipMemcpyAsync(terminated, env->term.p, env->N, hipMemcpyDeviceToHost, e->stream));
+    return qe_env_observe(env, obs, masks, nullptr);
+}
+
+// ---- fused rollout / evaluation ------------------------------------------------------------------
+static int run(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int mode,
+               int learn, int32_t* trace, qe_rollout_stats* st) {
+    if (!e || !env || env->e != e) return fail(QE_ERR_INVALID, "engine/env mismatch");
+    if (steps < 0) return fail(QE_ERR_INVALID, "steps must be >= 0");
+    if (st) memset(st, 0, sizeof *st);
+    e->ep_host.clear();
+    if (steps == 0) return QE_OK;
+    if (learn && (!eps || !lr)) return fail(QE_ERR_INVALID, "eps and lr schedules are required");
+    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rc = upload_schedules(e, steps, learn ? eps : nullptr, learn ? lr : nullptr)) return rc;
+    return e->dtype == QE_F32 ? rollout_dispatch<float>(e, env, steps, mode, learn, trace, st)
+                              : rollout_dispatch<double>(e, env, steps, mode, learn, trace, st);
+}
+
+int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int32_t mode,
+               int32_t* trace_actions, qe_rollout_stats* stats) {
+    return run(e, env, steps, eps, lr, mode, 1, trace_actions, stats);
+}
+
+int qe_evaluate(qe_engine* e, qe_env* env, int64_t steps, qe_rollout_stats* stats) {
+    return run(e, env, steps, nullptr, nullptr, QE_LEARN_ITER, 0, nullptr, stats);
+}
+
+int64_t qe_episode_log(qe_engine* e, int64_t cap, int32_t* step, int32_t* agent, float* ret) {
+    const int64_t n = (int64_t)e->ep_host.size();
+    for (int64_t k = 0; k < n && k < cap; ++k) {
+        if (step) step[k] = (int32_t)(e->ep_host[(size_t)k].first >> 32);
+        if (agent) agent[k] = (int32_t)(e->ep_host[(size_t)k].first & 0xFFFFFFFFull);
+        if (ret) ret[k] = e->ep_host[(size_t)k].second;
+    }
+    return n;
+}
+
+// ---- multi-GPU replica sync --------------------------------------------------------------------
+int qe_delta_log_attach(qe_engine* e, void* dev_buf, int64_t capacity) {
+    if (e->dtype != QE_F32 && dev_buf) return fail(QE_ERR_UNSUPPORTED, "delta log needs a float32 table");
+    e->dlog = (DeltaEntry*)dev_buf;
+    e->dlog_cap = dev_buf ? capacity : 0;
+    e->dlog_count = 0;
+    return QE_OK;
+}
+int64_t qe_delta_log_count(qe_engine* e) { return e->dlog_count; }
+int qe_delta_log_reset(qe_engine* e) { e->dlog_count = 0; return QE_OK; }
+
+int qe_delta_apply_dev(qe_engine* e, const void* dev_entries, int64_t count) {
+    if (count <= 0) return QE_OK;
+    if (e->dtype != QE_F32) return fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_delta_apply<float>, dim3(grid_for(count, 256)), dim3(256), 0, e->stream,
+                       (float*)e->q, (const DeltaEntry*)dev_entries, count);
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,163 @@
+/*
+ * qlearn_engine.h -- C ABI of the MI355X (gfx950) tabular Q-learning engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of dist_classicrl: batched env.step() ->
+ * epsilon-greedy (masked) arg-max -> TD target -> update of Q[s,a], with the Q-table resident in
+ * HBM.  The reference has no FFI layer (it is pure Python/NumPy); each entry point below names the
+ * reference interface it stands in for, paths relative to /root/reference/src/dist_classicrl/.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a HOST pointer unless the name ends in _dev.
+ *   - every call returns 0 on success or a negative qe_status; qe_last_error() gives the text
+ *     (thread-local).  The handle is NOT thread-safe (one host thread per engine, as the
+ *     reference's single_thread runtime).
+ *   - `states`/`actions` are int32 like the reference's NDArray[np.int32]; rewards float32;
+ *     `terminated` and action masks are one byte per element (non-zero = true / valid).
+ *   - table layout in HBM: row-major (state, action), row stride `ld` = action_size rounded up to a
+ *     multiple of 4 elements (so every row starts 16-byte aligned for float4 loads).
+ *   - randomness is counter based: Philox4x32-10, key = seed, counter = (agent, step, stream).
+ *     One "vector step" (one choose_actions call, or one step of a rollout) consumes one step
+ *     index; see oracle/draws.py for the exact protocol.
+ */
+#ifndef QLEARN_ENGINE_H
+#define QLEARN_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QE_ABI_VERSION 1
+
+typedef struct qe_engine qe_engine;
+typedef struct qe_env qe_env;
+
+enum qe_status {
+    QE_OK = 0,
+    QE_ERR_INVALID = -1,     /* bad argument (maps to Python ValueError / AssertionError) */
+    QE_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime error */
+    QE_ERR_OOM = -3,
+    QE_ERR_UNSUPPORTED = -4, /* shape outside what a fused kernel supports */
+    QE_ERR_INDEX = -5        /* state/action index out of range (NumPy would raise IndexError) */
+};
+
+enum qe_dtype { QE_F32 = 0, QE_F64 = 1 };
+
+/* Update semantics of a batch of transitions.
+ *   QE_LEARN_ITER : algorithms/base_algorithms/q_learning_optimal.py:770-817 (learn_iter, what
+ *                   `learn` :893-934 dispatches to): strictly sequential over agents.
+ *   QE_LEARN_VEC  : :819-891 (learn_vec / _learn_vec + add_q_values :235-250): all reads precede
+ *                   all writes, colliding updates accumulate (atomicAdd on device). */
+enum qe_learn_mode { QE_LEARN_ITER = 0, QE_LEARN_VEC = 1 };
+
+enum qe_env_kind {
+    QE_ENV_HASH = 0,  /* HashTabularEnv (build-defined synthetic MDP) */
+    QE_ENV_GRID = 1,  /* GridLakeEnv: FrozenLake-style side x side grid */
+    QE_ENV_BANDIT = 2 /* environments/rigged_two_armed_bandit.py:55-80 */
+};
+
+typedef struct qe_env_params {
+    int32_t kind;          /* qe_env_kind */
+    int32_t masked;        /* HASH only: observations carry an action mask */
+    uint32_t seed;         /* HASH, GRID */
+    int32_t p_term_256;    /* HASH: terminate when (hash & 0xff) < p_term_256 */
+    int32_t side;          /* GRID */
+    int32_t episode_len;   /* BANDIT */
+    uint32_t agent_offset; /* global id of local agent 0 (multi-GPU sharding of agents) */
+    int32_t reserved;
+} qe_env_params;
+
+typedef struct qe_rollout_stats {
+    double kernel_ms;        /* HIP-event time of the timed region on the engine's stream */
+    int64_t launches;        /* kernel launches issued (graph nodes count individually) */
+    int64_t episodes;        /* episodes that ended during this rollout */
+    int64_t involved;        /* agent-steps that went through the ordered (contested) path */
+    int64_t episodes_dropped; /* episode-log overflow (0 unless capacity was exceeded) */
+} qe_rollout_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------------
+ * qe_create      <- OptimalQLearningBase.__init__ (q_learning_optimal.py:84-98): zero (S, A) table,
+ *                   seeds the draw protocol.  `device` = HIP device ordinal. */
+int qe_abi_version(void);
+const char* qe_last_error(void);
+int qe_create(qe_engine** out, int64_t state_size, int32_t action_size, double discount_factor,
+              uint64_t seed, int32_t dtype, int32_t device);
+int qe_destroy(qe_engine* e);
+int qe_synchronize(qe_engine* e);
+/* Use the caller's HIP stream (hipStream_t as void*) instead of the engine's own. */
+int qe_set_stream(qe_engine* e, void* hip_stream);
+
+/* ---- Q-table I/O ----------------------------------------------------------------------------
+ * q_table property / save (q_learning_optimal.py:96, 252-261), parallel_runtime.py:70-77,171-176
+ * (rebind / copy back).  host buffers are C-contiguous (S, A) of `host_dtype`. */
+int qe_table_upload(qe_engine* e, const void* host, int32_t host_dtype);
+int qe_table_download(qe_engine* e, void* host, int32_t host_dtype);
+/* get_q_values / set_q_value(s) / add_q_values (:100-250); add follows np.add.at (duplicates
+ * accumulate in index order). op: 0 = read into vals, 1 = write, 2 = add. */
+int qe_table_cells(qe_engine* e, const int32_t* states, const int32_t* actions, int64_t n,
+                   double* vals, int32_t op);
+void* qe_table_dev(qe_engine* e);       /* device pointer of the table (for RCCL plumbing) */
+int64_t qe_table_row_stride(qe_engine* e); /* ld, in elements */
+
+/* ---- draw counter ---------------------------------------------------------------------------*/
+int qe_set_step_counter(qe_engine* e, uint64_t step);
+uint64_t qe_get_step_counter(qe_engine* e);
+int qe_set_agent_offset(qe_engine* e, uint32_t offset); /* draw-protocol id of local agent 0 */
+
+/* ---- action selection -----------------------------------------------------------------------
+ * choose_actions and all eight variants behind it (q_learning_optimal.py:263-726): one kernel
+ * family, same distribution, draws per oracle/draws.py.  masks: n*A bytes or NULL.
+ * Returns -1 in out_actions[i] when agent i has no selectable action (as :302, :348).
+ * Consumes one step index. */
+int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint8_t* masks,
+                      double exploration_rate, int32_t deterministic, int32_t* out_actions);
+
+/* ---- learning -------------------------------------------------------------------------------
+ * learn / learn_iter / learn_vec (q_learning_optimal.py:770-934). next_masks: n*A bytes or NULL. */
+int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const float* rewards,
+             const int32_t* next_states, const uint8_t* terminated, int64_t n, double lr,
+             const uint8_t* next_masks, int32_t mode);
+
+/* ---- device-resident environments + fused rollout -------------------------------------------
+ * The batched env contract (environments/custom_env.py:31-84) as realised by
+ * SyncVectorEnv(SAME_STEP) (benchmarks/throughput_benchmark.py:109-123). */
+int qe_env_create(qe_env** out, qe_engine* e, int64_t num_agents, const qe_env_params* p);
+int qe_env_destroy(qe_env* env);
+int qe_env_reset(qe_env* env, int32_t has_seed, uint32_t seed);
+/* current observations (+ masks n*A bytes, + per-agent running episode returns); any may be NULL */
+int qe_env_observe(qe_env* env, int32_t* obs, uint8_t* masks, float* agent_rewards);
+/* restore observations / env-internal counters / running returns (resume, curr_state_dict) */
+int qe_env_restore(qe_env* env, const int32_t* obs, const uint32_t* aux, const float* agent_rewards);
+int qe_env_aux(qe_env* env, uint32_t* aux);
+/* host-driven env.step (actions in, transition out); outputs may be NULL */
+int qe_env_step(qe_env* env, const int32_t* actions, int32_t* obs, float* rewards,
+                uint8_t* terminated, uint8_t* masks);
+
+/* qe_rollout <- SingleThreadQLearning.run_steps hot loop (single_thread_runtime.py:63-64) =
+ * `steps` x BaseRuntime.run_single_step (base_runtime.py:184-222) incl. _learn's schedule reads
+ * (:224-263).  eps[t], lr[t] are the schedule values the reference would read at vector step t.
+ * trace_actions: optional host buffer steps*n int32 receiving every selected action (tests). */
+int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
+               int32_t mode, int32_t* trace_actions, qe_rollout_stats* stats);
+/* qe_evaluate <- BaseRuntime.evaluate_steps / evaluate_episodes (base_runtime.py:293-384): greedy,
+ * no learning.  Runs `steps` vector steps. */
+int qe_evaluate(qe_engine* e, qe_env* env, int64_t steps, qe_rollout_stats* stats);
+/* Episode log of the last rollout/evaluate: (vector step within the call, agent, return), sorted
+ * by (step, agent) = the order base_runtime.py:218-221 appends.  Returns the count; copies at most
+ * `cap` entries. */
+int64_t qe_episode_log(qe_engine* e, int64_t cap, int32_t* step, int32_t* agent, float* ret);
+
+/* ---- multi-GPU replica sync (replaces the MPI tier, q_learning_async_dist.py:164-357) ---------
+ * Each GPU logs (cell, delta) for its own updates into a caller-owned device buffer of
+ * capacity entries x 8 bytes {uint32 cell; float delta}; remote logs are applied with atomicAdd. */
+int qe_delta_log_attach(qe_engine* e, void* dev_buf, int64_t capacity);
+int64_t qe_delta_log_count(qe_engine* e);
+int qe_delta_log_reset(qe_engine* e);
+int qe_delta_apply_dev(qe_engine* e, const void* dev_entries, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QLEARN_ENGINE_H */

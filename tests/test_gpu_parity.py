@@ -1,0 +1,219 @@
+"""GPU parity tests: the HIP engine, called through the C ABI (ctypes), against
+
+* the golden vectors produced by the real reference (bit-exact actions AND bit-exact Q-values in
+  both table dtypes -- tighter than the 1e-6 the north star asks for);
+* the oracle on seeded inputs at sizes it finishes in seconds;
+* size-independent properties at BASELINE.json's full sizes.
+
+Nothing here reads /root/reference (it does not exist on the GPU box).
+"""
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, TRACE_CASES, dense_from_sparse, run_oracle_trace, schedule_params
+from golden.make_golden_cases import LEARN_CASES, SELECT_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def _product():
+    from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
+    from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
+    from dist_classicrl_amd import environments, schedules
+
+    return OptimalQLearningBase, GpuRolloutQLearning, environments, schedules
+
+
+def make_device_env(spec):
+    _, _, envs, _ = _product()
+    if spec[0] == "hash":
+        _, n, S, A, masked = spec
+        return envs.HashTabularEnv(n, S, A, seed=1, masked=masked)
+    if spec[0] == "grid":
+        return envs.GridLakeEnv(spec[1], side=spec[2], seed=1)
+    return envs.RiggedTwoArmedBanditVecEnv(spec[1], episode_len=spec[2])
+
+
+def make_schedule(p):
+    _, _, _, sch = _product()
+    kind, value, lo, decay = p
+    if kind == "exponential":
+        return sch.ExponentialSchedule(value, lo, decay)
+    if kind == "linear":
+        return sch.LinearSchedule(value, decay)
+    return sch.ConstantSchedule(value)
+
+
+# ------------------------------------------------------------------------------- selection
+@pytest.mark.parametrize("k", range(len(SELECT_CASES)))
+def test_select_matches_reference_golden(k):
+    Algo = _product()[0]
+    g = np.load(GOLDEN / "select.npz")
+    method = SELECT_CASES[k][0]
+    S, A, n, masked, det, seed = (int(v) for v in g[f"c{k}_meta"])
+    eps, step = float(g[f"c{k}_eps"][0]), int(g[f"c{k}_step"][0])
+    q = g[f"c{k}_q"]
+    algo = Algo(S, A, 0.9, seed=seed, dtype=q.dtype)
+    algo.q_table = q
+    algo.step_counter = step
+    masks = g[f"c{k}_masks"] if masked else None
+    if method == "choose_actions_vec":
+        acts = algo.choose_actions_vec(g[f"c{k}_states"], eps, deterministic=bool(det))
+    elif method == "choose_masked_actions_vec":
+        acts = algo.choose_masked_actions_vec(g[f"c{k}_states"], masks, eps, deterministic=bool(det))
+    else:
+        acts = getattr(algo, method)(g[f"c{k}_states"], eps, deterministic=bool(det), action_masks=masks)
+    assert acts.dtype == np.int32
+    assert np.array_equal(acts, g[f"c{k}_actions"])  # bit-exact action indices
+    assert algo.step_counter == step + 1
+
+
+# ------------------------------------------------------------------------------- learning
+@pytest.mark.parametrize("k", range(len(LEARN_CASES)))
+@pytest.mark.parametrize("fn", ["learn", "learn_vec"])
+def test_learn_matches_reference_golden(k, fn):
+    Algo = _product()[0]
+    g = np.load(GOLDEN / "learn.npz")
+    S, A, n, masked = (int(v) for v in g[f"c{k}_meta"])
+    lr, gamma = (float(v) for v in g[f"c{k}_hyper"])
+    q0 = g[f"c{k}_q0"]
+    algo = Algo(S, A, gamma, seed=0, dtype=q0.dtype)
+    algo.q_table = q0
+    masks = g[f"c{k}_masks"] if masked else None
+    getattr(algo, fn)(g[f"c{k}_states"], g[f"c{k}_actions"], g[f"c{k}_rewards"], g[f"c{k}_next_states"],
+                      g[f"c{k}_terminated"], lr, masks)
+    got, want = np.asarray(algo.q_table), g[f"c{k}_q_{fn}"]
+    assert got.dtype == want.dtype
+    if fn == "learn":
+        assert np.array_equal(got, want)  # sequential semantics: bit-exact
+    else:
+        # colliding increments are accumulated with atomicAdd: the order of the additions is not
+        # fixed, everything else is bit-exact.  Tolerance: 1e-6 relative (north star), fp32.
+        same = got == want
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+        s, a = g[f"c{k}_states"], g[f"c{k}_actions"]
+        cells, counts = np.unique(s.astype(np.int64) * A + a, return_counts=True)
+        dup = np.zeros(S * A, dtype=bool)
+        dup[cells[counts > 1]] = True
+        assert same.ravel()[~dup].all()  # cells without colliding updates are bit-exact
+
+
+# ------------------------------------------------------------------------------- closed loop
+def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0):
+    Algo, Runtime, _, _ = _product()
+    env = make_device_env(spec)
+    algo = Algo(env.state_size, env.action_size, gamma, seed=seed, dtype=np.dtype(dt))
+    lr_p, eps_p = schedule_params(sched)
+    rt = Runtime(algo, make_schedule(lr_p), make_schedule(eps_p), learn_mode=mode)
+    rt.trace_actions = True
+    try:
+        _avg, history, _env, sd = rt.run_steps(steps, env, None)
+    except ZeroDivisionError:  # reference quirk when no episode ends; state is still valid
+        history = []
+        sd = None
+    obs, acc = env.observe()
+    return {
+        "actions": rt.trace_actions,
+        "q": np.asarray(algo.q_table),
+        "history": np.array(history, dtype=np.float32),
+        "final_obs": obs["observation"] if isinstance(obs, dict) else obs,
+        "agent_rewards": acc,
+        "final_sched": np.array([rt.lr_schedule.get_value(), rt.exploration_rate_schedule.get_value()]),
+        "stats": rt.last_stats,
+        "state_dict": sd,
+    }
+
+
+@pytest.mark.parametrize("name", list(TRACE_CASES))
+def test_rollout_matches_reference_golden(name):
+    g = np.load(GOLDEN / "traces.npz")
+    spec, steps, dt, sched, mode = TRACE_CASES[name]
+    got = _run_product_trace(spec, steps, dt, sched, mode)
+    assert np.array_equal(got["actions"], g[f"{name}/actions"])  # every action of every step
+    want_q = dense_from_sparse(g[f"{name}/q_idx"], g[f"{name}/q_val"], got["q"].shape, got["q"].dtype)
+    if mode == "iter":
+        assert np.array_equal(got["q"], want_q)
+    else:
+        assert np.allclose(got["q"], want_q, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(got["history"], g[f"{name}/history"])
+    assert np.array_equal(got["final_obs"], g[f"{name}/final_obs"])
+    assert np.array_equal(got["agent_rewards"], g[f"{name}/agent_rewards"])
+    assert np.array_equal(got["final_sched"], g[f"{name}/final_sched"])
+
+
+@pytest.mark.parametrize(
+    ("spec", "steps", "dt", "mode"),
+    [
+        (("hash", 1024, 5000, 16, False), 30, "f4", "iter"),
+        (("hash", 1024, 5000, 16, False), 30, "f8", "iter"),
+        (("hash", 4096, 300, 8, False), 12, "f4", "iter"),  # > 2048 involved agents: sequential path
+        (("hash", 512, 2000, 64, True), 20, "f4", "iter"),
+        (("hash", 300, 100000, 32, False), 25, "f4", "iter"),
+        (("hash", 700, 1000, 4, False), 25, "f8", "iter"),
+        (("hash", 1000, 200, 12, True), 10, "f4", "iter"),
+        (("grid", 200, 6), 40, "f4", "iter"),
+        (("bandit", 300, 4), 12, "f8", "iter"),
+    ],
+)
+def test_rollout_matches_oracle_seeded(spec, steps, dt, mode):
+    want = run_oracle_trace(spec, steps, dt, "const", mode)
+    got = _run_product_trace(spec, steps, dt, "const", mode)
+    assert np.array_equal(got["actions"], want["actions"])
+    assert np.array_equal(got["q"], want["q"])
+    assert np.array_equal(got["history"], want["history"])
+    assert np.array_equal(got["final_obs"], want["final_obs"])
+    assert np.array_equal(got["agent_rewards"], want["agent_rewards"])
+
+
+def test_rollout_resume_equals_one_shot():
+    """run_steps(a) then run_steps(b, curr_state_dict) == run_steps(a+b) (single_thread_runtime.py:58-61)."""
+    spec = ("hash", 256, 3000, 16, False)
+    one = _run_product_trace(spec, 40, "f4", "bench", "iter")
+    Algo, Runtime, _, _ = _product()
+    env = make_device_env(spec)
+    algo = Algo(env.state_size, env.action_size, 0.99, seed=0)
+    lr_p, eps_p = schedule_params("bench")
+    rt = Runtime(algo, make_schedule(lr_p), make_schedule(eps_p))
+    _, h1, env, sd = rt.run_steps(15, env, None)
+    _, h2, env, sd = rt.run_steps(25, env, sd)
+    assert np.array_equal(np.asarray(algo.q_table), one["q"])
+    assert np.array_equal(np.array(h1 + h2, dtype=np.float32), one["history"])
+    assert np.array_equal(sd["states"], one["final_obs"])
+
+
+# ------------------------------------------------------------------------------- full sizes
+@pytest.mark.parametrize(
+    ("n", "S", "A", "masked"),
+    [(128, 10_000, 8, False), (4096, 1_000_000, 16, False), (1024, 1_000_000, 64, True),
+     (128, 1_000_000, 16, False)],
+)
+def test_full_size_properties(n, S, A, masked):
+    """BASELINE configs 2, 3, 5 and the headline shape: properties that do not need the oracle."""
+    Algo, Runtime, envs, sch = _product()
+    algo = Algo(S, A, 0.99, seed=0)
+    env = envs.HashTabularEnv(n, S, A, seed=1, masked=masked)
+    rt = Runtime(algo, sch.ConstantSchedule(0.1), sch.ConstantSchedule(0.1))
+    steps = 200
+    _avg, history, _, sd = rt.run_steps(steps, env, None)
+    q = np.asarray(algo.q_table)
+    assert np.isfinite(q).all()
+    # rewards are in [0, 1): Q is bounded by the geometric series, and never negative
+    assert q.min() >= 0.0 and q.max() <= 1.0 / (1.0 - 0.99)
+    # at most one cell is written per agent-step
+    assert np.count_nonzero(q) <= n * steps
+    # episode accounting: every env-step's reward is either in a finished episode or still pending
+    obs = sd["states"]["observation"] if masked else sd["states"]
+    assert obs.min() >= 0 and obs.max() < S
+    assert len(history) == rt.last_stats["episodes"] and rt.last_stats["episodes_dropped"] == 0
+    # determinism: the exact-sequential mode is bit-reproducible run to run
+    algo2 = Algo(S, A, 0.99, seed=0)
+    env2 = envs.HashTabularEnv(n, S, A, seed=1, masked=masked)
+    rt2 = Runtime(algo2, sch.ConstantSchedule(0.1), sch.ConstantSchedule(0.1))
+    _, history2, _, _ = rt2.run_steps(steps, env2, None)
+    assert np.array_equal(np.asarray(algo2.q_table), q)
+    assert np.array_equal(np.array(history2), np.array(history))
+    # greedy evaluation leaves the table untouched
+    val = envs.HashTabularEnv(n, S, A, seed=1, masked=masked)
+    rt.evaluate_steps(val, 20 * n)
+    assert np.array_equal(np.asarray(algo.q_table), q)
