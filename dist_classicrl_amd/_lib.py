@@ -12,11 +12,16 @@ from pathlib import Path
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libqlearn_engine.so"
+import os
+
+# QE_LIB_PATH lets a developer A/B two builds of the library in one session; default = in-tree build
+LIB_PATH = Path(os.environ.get("QE_LIB_PATH") or Path(__file__).resolve().parent / "csrc" / "libqlearn_engine.so")
 
 QE_F32, QE_F64 = 0, 1
 LEARN_ITER, LEARN_VEC = 0, 1
 ENV_HASH, ENV_GRID, ENV_BANDIT = 0, 1, 2
+OPT_ROLLOUT_PATH = 0
+PATH_AUTO, PATH_STEPWISE, PATH_PERSISTENT = 0, 1, 2
 
 ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INDEX = -1, -2, -3, -4, -5
 
@@ -45,6 +50,9 @@ class RolloutStats(C.Structure):
         ("episodes", C.c_int64),
         ("involved", C.c_int64),
         ("episodes_dropped", C.c_int64),
+        ("dominant_ms", C.c_double),
+        ("dominant_launches", C.c_int64),
+        ("dominant_env_steps", C.c_int64),
     ]
 
 
@@ -63,6 +71,7 @@ PROTOTYPES = {
     "qe_destroy": (C.c_int, [_P]),
     "qe_synchronize": (C.c_int, [_P]),
     "qe_set_stream": (C.c_int, [_P, _P]),
+    "qe_set_option": (C.c_int, [_P, C.c_int32, C.c_int64]),
     "qe_table_upload": (C.c_int, [_P, _P, C.c_int32]),
     "qe_table_download": (C.c_int, [_P, _P, C.c_int32]),
     "qe_table_cells": (C.c_int, [_P, _I32P, _I32P, C.c_int64, _F64P, C.c_int32]),

@@ -91,6 +91,20 @@ class OptimalQLearningBase:
     def step_counter(self, value: int) -> None:
         _lib.check(self._lib.qe_set_step_counter(self._h, int(value)))
 
+    def set_rollout_path(self, path: str) -> None:
+        """Tuning knob, never changes results: ``"auto"``, ``"stepwise"`` (one kernel pair per vector
+        step) or ``"persistent"`` (one launch per rollout; needs agents x lanes-per-row <= 1024)."""
+        code = {"auto": _lib.PATH_AUTO, "stepwise": _lib.PATH_STEPWISE, "persistent": _lib.PATH_PERSISTENT}[path]
+        _lib.check(self._lib.qe_set_option(self._h, _lib.OPT_ROLLOUT_PATH, code))
+
+    @property
+    def lanes_per_row(self) -> int:
+        """Lanes of a wavefront that share one Q-table row (power of two, 4 columns per lane)."""
+        ld, lanes = int(self._lib.qe_table_row_stride(self._h)), 1
+        while 4 * lanes < ld and lanes < 64:
+            lanes *= 2
+        return lanes
+
     def _qe_dtype(self, dt):
         return _lib.QE_F32 if np.dtype(dt) == np.float32 else _lib.QE_F64
 

@@ -44,6 +44,8 @@ class GpuRolloutQLearning(BaseRuntime):
             raise ValueError(msg)
         self.learn_mode = learn_mode
         self.last_stats = None  # accumulated qe_rollout_stats of the latest run_steps call
+        self.delta_sync = None  # dist_classicrl_amd.distributed.DeltaSync (multi-GPU replicas)
+        self.sync_every = 100
         self.trace_actions = None  # set to True to collect every action (tests)
 
     def init_training(self) -> None:
@@ -63,9 +65,12 @@ class GpuRolloutQLearning(BaseRuntime):
         algo = self.algorithm
         n = env.num_agents
         mode = _lib.LEARN_ITER if self.learn_mode == "iter" else _lib.LEARN_VEC
-        total = {"kernel_ms": 0.0, "launches": 0, "episodes": 0, "involved": 0, "episodes_dropped": 0}
+        total = {"kernel_ms": 0.0, "launches": 0, "episodes": 0, "involved": 0, "episodes_dropped": 0,
+                 "dominant_ms": 0.0, "dominant_launches": 0, "dominant_env_steps": 0}
         history, ep_steps, traces = [], [], []
         chunk_max = max(1, _EP_LOG_CAPACITY // n)
+        if learn and self.delta_sync is not None:
+            chunk_max = min(chunk_max, self.sync_every)
         done = 0
         while done < steps:
             k = min(chunk_max, steps - done)
@@ -79,6 +84,10 @@ class GpuRolloutQLearning(BaseRuntime):
                                           C.byref(st)))
                 if trace is not None:
                     traces.append(trace)
+                if self.delta_sync is not None:
+                    # replicas exchange the (cell, delta) records of this chunk (RCCL all-gather)
+                    self.delta_sync.exchange(int(lib.qe_delta_log_count(algo.handle)))
+                    _lib.check(lib.qe_delta_log_reset(algo.handle))
             else:
                 _lib.check(lib.qe_evaluate(algo.handle, env.handle, k, C.byref(st)))
             cnt = int(lib.qe_episode_log(algo.handle, 0, None, None, None))

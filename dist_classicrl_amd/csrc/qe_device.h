@@ -109,15 +109,23 @@ __device__ __forceinline__ Row4<T> load_row4_live(const T* q, int64_t row, int l
     return r;
 }
 
-template <typename T>
+// Lane-group reductions.  `LC` > 0 fixes the group width at compile time (the shuffles then lower to
+// DPP moves instead of LDS-crossbar ds_bpermute, which matters in the latency-bound persistent
+// kernel); LC == 0 takes the runtime width `L`.
+template <int LC = 0, typename T>
 __device__ __forceinline__ T group_max(T v, int L) {
+    if (LC) L = LC;
+#pragma unroll
     for (int off = L >> 1; off > 0; off >>= 1) {
         const T o = __shfl_xor(v, off, L);
         v = o > v ? o : v;
     }
     return v;
 }
+template <int LC = 0>
 __device__ __forceinline__ int group_max_int(int v, int L) {
+    if (LC) L = LC;
+#pragma unroll
     for (int off = L >> 1; off > 0; off >>= 1) {
         const int o = __shfl_xor(v, off, L);
         v = o > v ? o : v;
@@ -126,13 +134,13 @@ __device__ __forceinline__ int group_max_int(int v, int L) {
 }
 
 // max over the valid columns of this lane's 4 elements, reduced over the group (-inf if none).
-template <typename T>
+template <int LC = 0, typename T>
 __device__ __forceinline__ T row_max_valid(const Row4<T>& row, uint32_t valid4, int L) {
     T m = neg_inf<T>();
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if ((valid4 >> j) & 1u) m = row.v[j] > m ? row.v[j] : m;
-    return group_max(m, L);
+    return group_max<LC>(m, L);
 }
 
 // columns < A of this lane, as a 4-bit field
@@ -145,10 +153,11 @@ __device__ __forceinline__ uint32_t in_range4(int sub, int A) {
 // q_learning_optimal.py:263-642): explore -> k-th valid action, k = mulhi(x1, n_valid);
 // greedy -> k-th action tied at the valid maximum, k = mulhi(x2, n_ties).  Returns -1 when no
 // action is selectable.  *picked_q receives Q[s, action] as held in `row`.
-template <typename T>
+template <int LC = 0, typename T>
 __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4, int sub, int L,
                                              bool explore, uint32_t x1, uint32_t x2, T* picked_q) {
-    const T m = row_max_valid(row, valid4, L);
+    if (LC) L = LC;
+    const T m = row_max_valid<LC>(row, valid4, L);
     uint32_t f = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -157,6 +166,7 @@ __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4
     }
     const int cnt = __popc(f);
     int incl = cnt;
+#pragma unroll
     for (int off = 1; off < L; off <<= 1) {
         const int t = __shfl_up(incl, off, L);
         if (sub >= off) incl += t;
@@ -172,7 +182,7 @@ __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4
             act = 4 * sub + (__ffs(g) - 1);
         }
     }
-    act = group_max_int(act, L);
+    act = group_max_int<LC>(act, L);
     const int jj = act & 3;
     const T mine = jj == 0 ? row.v[0] : (jj == 1 ? row.v[1] : (jj == 2 ? row.v[2] : row.v[3]));
     *picked_q = __shfl(mine, act < 0 ? 0 : (act >> 2), L);
@@ -187,7 +197,10 @@ __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4
 // ITER = single_learn (q_learning_optimal.py:728-768) under NEP-50 promotion:
 //        t = g*m ; y = r + t ; d = y - q ; u = lr*d ; q' = q + u          (all in the table dtype)
 // VEC  = _learn_vec (:819-891): on a float32 table `(1 - terminated)` is int64, which promotes the
-//        target to float64; the increment is rounded to float32 once by np.add.at.
+//        target to float64, and np.add.at (:249) adds the float64 increment to the float32 cell in
+//        float64 before rounding once: q' = (float)((double)q + lr*(y - q)).
+// `apply` returns the new cell value (exclusive writer); `delta` the increment handed to
+// atomicAdd when several transitions of one batch collide on a cell (VEC only).
 struct Hyper {
     double gamma, lr;
     float gamma32, lr32;
@@ -198,30 +211,45 @@ struct Td;
 
 template <>
 struct Td<float> {
-    static __device__ __forceinline__ float delta(float q, float r, float m, bool term,
-                                                  const Hyper& h, int mode) {
-        if (mode == 0) {
-            const float t = term ? 0.0f : h.gamma32 * m;
-            const float y = r + t;
-            const float d = y - q;
-            return h.lr32 * d;
-        }
+    static __device__ __forceinline__ double vec_inc(float q, float r, float m, bool term, const Hyper& h) {
         const float t32 = h.gamma32 * m;
         const double t = term ? 0.0 : (double)t32;
         const double y = (double)r + t;
         const double d = y - (double)q;
-        return (float)(h.lr * d);
+        return h.lr * d;
+    }
+    static __device__ __forceinline__ float apply(float q, float r, float m, bool term,
+                                                  const Hyper& h, int mode, float* inc) {
+        if (mode == 0) {
+            const float t = term ? 0.0f : h.gamma32 * m;
+            const float y = r + t;
+            const float d = y - q;
+            const float u = h.lr32 * d;
+            *inc = u;
+            return q + u;
+        }
+        const double u = vec_inc(q, r, m, term, h);
+        *inc = (float)u;
+        return (float)((double)q + u);
+    }
+    static __device__ __forceinline__ float delta(float q, float r, float m, bool term, const Hyper& h) {
+        return (float)vec_inc(q, r, m, term, h);
     }
 };
 
 template <>
 struct Td<double> {
-    static __device__ __forceinline__ double delta(double q, float r, double m, bool term,
-                                                   const Hyper& h, int /*mode*/) {
+    static __device__ __forceinline__ double delta(double q, float r, double m, bool term, const Hyper& h) {
         const double t = term ? 0.0 : h.gamma * m;
         const double y = (double)r + t;
         const double d = y - q;
         return h.lr * d;
+    }
+    static __device__ __forceinline__ double apply(double q, float r, double m, bool term,
+                                                   const Hyper& h, int /*mode*/, double* inc) {
+        const double u = delta(q, r, m, term, h);
+        *inc = u;
+        return q + u;
     }
 };
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "qe_kernels.h"
@@ -74,10 +75,11 @@ struct qe_engine {
     double gamma = 0.97;
     uint64_t seed = 0, step_ctr = 0;
     uint32_t agent_offset = 0;
+    int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
     hipStream_t stream = nullptr;
     bool own_stream = true;
     void* q = nullptr;
-    uint32_t* stamps = nullptr;
+    unsigned long long* stamps = nullptr;
     Ctrl* ctrl = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // schedules
@@ -88,7 +90,7 @@ struct qe_engine {
     DevBuf<float> b_r, b_acc;
     DevBuf<uint8_t> b_term, b_pred;
     DevBuf<uint32_t> b_aux, b_mask, b_bitmap;
-    DevBuf<double> b_vals;
+    DevBuf<double> b_vals, b_vinc;
     // episode log
     DevBuf<unsigned long long> ep_key;
     DevBuf<float> ep_ret;
@@ -98,6 +100,7 @@ struct qe_engine {
     DeltaEntry* dlog = nullptr;
     long long dlog_cap = 0, dlog_count = 0;
     DevBuf<int32_t> trace;
+    std::vector<hipEvent_t> sample_ev;  // event pairs around sampled dominant-kernel launches
     size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
 };
 
@@ -109,6 +112,7 @@ struct qe_env {
     DevBuf<float> r, acc;
     DevBuf<uint8_t> term, pred, masks;
     DevBuf<uint32_t> aux, bitmap;
+    DevBuf<double> vinc;
 };
 
 namespace {
@@ -145,7 +149,7 @@ Ctx<T> env_ctx(qe_engine* e, qe_env* env) {
     Ctx<T> c = base_ctx<T>(e, env->N);
     c.s = env->s.p; c.a = env->a.p; c.n = env->n.p; c.r = env->r.p; c.term = env->term.p;
     c.pred = (T*)env->pred.p; c.aux = env->aux.p; c.acc = env->acc.p;
-    c.inv_bitmap = env->bitmap.p; c.inv_list = env->list.p;
+    c.inv_bitmap = env->bitmap.p; c.inv_list = env->list.p; c.vinc = env->vinc.p;
     c.agent_offset = env->p.agent_offset;
     return c;
 }
@@ -184,10 +188,15 @@ void pack_masks(const uint8_t* masks, int64_t n, int A, std::vector<uint32_t>& o
             if (masks[i * A + j]) out[(size_t)i * nw + (j >> 5)] |= 1u << (j & 31);
 }
 
+constexpr int MAX_SAMPLES = 256;
+
 template <typename T, class Env>
-int launch_step(qe_engine* e, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow, int64_t* launches) {
+int launch_step(qe_engine* e, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow, int64_t* launches,
+                int sample = -1) {
+    if (sample >= 0) (void)hipEventRecord(e->sample_ev[2 * sample], e->stream);
     hipLaunchKernelGGL((k_step_fast<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK),
                        0, e->stream, c, ev, flags);
+    if (sample >= 0) (void)hipEventRecord(e->sample_ev[2 * sample + 1], e->stream);
     ++*launches;
     if (slow) {
         hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
@@ -215,12 +224,45 @@ int rollout_impl(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, 
     HIP_TRY(hipMemcpyAsync(e->ctrl, &init, sizeof init, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     int64_t launches = 0;
+    int n_samples = 0;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
-    if (learn) {
+    const int64_t lanes = env->N * e->L;
+    const bool persistent = learn && lanes <= PERSIST_MAX_LANES && env->N <= PERSIST_MAX_AGENTS && e->opt_path != 1;
+    if (learn && e->opt_path == 2 && !persistent)
+        return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and num_agents * lanes_per_row <= 1024 (have %lld lanes)",
+                    (long long)lanes);
+    if (persistent) {
+        const unsigned block = (unsigned)((lanes + 63) / 64 * 64);
+        auto go = [&](auto lc) {
+            hipLaunchKernelGGL((k_rollout_persistent<T, Env, decltype(lc)::value>), dim3(1), dim3(block), 0,
+                               e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+        };
+        if constexpr (std::is_same<Env, HashEnv>::value) {
+            switch (e->L) {  // compile-time lane-group width: reductions become DPP moves
+                case 1: go(std::integral_constant<int, 1>{}); break;
+                case 2: go(std::integral_constant<int, 2>{}); break;
+                case 4: go(std::integral_constant<int, 4>{}); break;
+                case 8: go(std::integral_constant<int, 8>{}); break;
+                case 16: go(std::integral_constant<int, 16>{}); break;
+                default: go(std::integral_constant<int, 0>{}); break;
+            }
+        } else {
+            go(std::integral_constant<int, 1>{});  // GridLake (A = 4) and the bandit (A = 2): one lane per row
+        }
+        ++launches;
+    } else if (learn) {
         const int base = FLAG_ACCOUNT;
-        launch_step<T, Env>(e, c, ev, base | FLAG_SELECT, false, &launches);  // select(0), env(0)
-        for (int64_t t = 0; t + 1 < steps; ++t)
-            launch_step<T, Env>(e, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, &launches);
+        launch_step<T, Env>(e, c, ev, base | FLAG_SELECT, false, &launches);  // select(0), env.step(0)
+        while ((int)e->sample_ev.size() < 2 * MAX_SAMPLES) {
+            hipEvent_t evn;
+            HIP_TRY(hipEventCreate(&evn));
+            e->sample_ev.push_back(evn);
+        }
+        const int64_t stride = std::max<int64_t>(1, (steps - 1) / MAX_SAMPLES);
+        for (int64_t t = 0; t + 1 < steps; ++t) {
+            const int sample = (t % stride == 0 && n_samples < MAX_SAMPLES) ? n_samples++ : -1;
+            launch_step<T, Env>(e, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, &launches, sample);
+        }
         launch_step<T, Env>(e, c, ev, base | FLAG_LEARN, true, &launches);  // learn(steps-1)
     } else {
         // greedy evaluation: no table writes, hence no contention and no ordered path
@@ -255,7 +297,27 @@ int rollout_impl(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, 
         st->kernel_ms = ms; st->launches = launches; st->episodes = (int64_t)fin.ep_count;
         st->involved = (int64_t)fin.involved_total;
         st->episodes_dropped = (int64_t)fin.ep_count - got;
+        for (int k = 0; k < n_samples; ++k) {
+            float one = 0;
+            if (hipEventElapsedTime(&one, e->sample_ev[2 * k], e->sample_ev[2 * k + 1]) == hipSuccess)
+                st->dominant_ms += one;
+        }
+        st->dominant_launches = n_samples;
+        st->dominant_env_steps = (int64_t)n_samples * env->N;
+        if (persistent) {  // the one launch IS the timed region
+            st->dominant_ms = ms; st->dominant_launches = 1; st->dominant_env_steps = steps * env->N;
+        }
     }
+#ifdef QE_STAMPS
+    if (persistent) {
+        double seg[8];
+        (void)hipMemcpy(seg, env->vinc.p, sizeof seg, hipMemcpyDeviceToHost);
+        const char* names[8] = {"inserts", "barrier", "row issue+classify", "philox", "update+account",
+                                "select+env", "extended+flush", "loop top"};
+        for (int k = 0; k < 8; ++k) fprintf(stderr, "  [stamps] %-20s %8.1f ns/step\n", names[k], seg[k] * 10.0 / steps);
+    }
+#endif
+    if (fin.error) return fail(QE_ERR_NO_DEVICE, "ordered path gave up (internal error %u)", fin.error);
     return QE_OK;
 }
 
@@ -318,14 +380,14 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     const size_t bytes = (size_t)S * e->ld * e->esize();
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipMalloc(&e->q, bytes);
-    if (err == hipSuccess) err = hipMalloc((void**)&e->stamps, (size_t)S * 2 * sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMalloc((void**)&e->stamps, (size_t)S * 2 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc((void**)&e->ctrl, sizeof(Ctrl));
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = e->ep_key.ensure((size_t)e->ep_cap);
     if (err == hipSuccess) err = e->ep_ret.ensure((size_t)e->ep_cap);
     if (err == hipSuccess) err = hipMemsetAsync(e->q, 0, bytes, e->stream);
-    if (err == hipSuccess) err = hipMemsetAsync(e->stamps, 0, (size_t)S * 2 * sizeof(uint32_t), e->stream);
+    if (err == hipSuccess) err = hipMemsetAsync(e->stamps, 0, (size_t)S * 2 * sizeof(unsigned long long), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
     if (err != hipSuccess) {
@@ -347,10 +409,11 @@ int qe_destroy(qe_engine* e) {
     if (e->ctrl) (void)hipFree(e->ctrl);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (hipEvent_t x : e->sample_ev) (void)hipEventDestroy(x);
     e->thr.release(); e->lr.release(); e->b_s.release(); e->b_a.release(); e->b_n.release();
     e->b_out.release(); e->b_list.release(); e->b_r.release(); e->b_acc.release(); e->b_term.release();
     e->b_pred.release(); e->b_aux.release(); e->b_mask.release(); e->b_bitmap.release();
-    e->b_vals.release(); e->ep_key.release(); e->ep_ret.release(); e->trace.release();
+    e->b_vals.release(); e->b_vinc.release(); e->ep_key.release(); e->ep_ret.release(); e->trace.release();
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return QE_OK;
@@ -359,6 +422,11 @@ int qe_destroy(qe_engine* e) {
 int qe_synchronize(qe_engine* e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     return QE_OK;
+}
+
+int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
+    if (option == QE_OPT_ROLLOUT_PATH && value >= 0 && value <= 2) { e->opt_path = (int)value; return QE_OK; }
+    return fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 
 int qe_set_stream(qe_engine* e, void* s) {
@@ -497,6 +565,7 @@ int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const 
     HIP_TRY(e->b_s.ensure(un)); HIP_TRY(e->b_a.ensure(un)); HIP_TRY(e->b_n.ensure(un));
     HIP_TRY(e->b_r.ensure(un)); HIP_TRY(e->b_term.ensure(un)); HIP_TRY(e->b_pred.ensure(un * 8));
     HIP_TRY(e->b_aux.ensure(un)); HIP_TRY(e->b_acc.ensure(un)); HIP_TRY(e->b_list.ensure(un));
+    HIP_TRY(e->b_vinc.ensure(un));
     const size_t words = (un + 31) / 32;
     if (words > e->b_bitmap.cap) {
         HIP_TRY(e->b_bitmap.ensure(words));
@@ -526,7 +595,7 @@ int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const 
         c.mode = mode;
         c.s = e->b_s.p; c.a = e->b_a.p; c.n = e->b_n.p; c.r = e->b_r.p; c.term = e->b_term.p;
         c.pred = (T*)e->b_pred.p; c.aux = e->b_aux.p; c.acc = e->b_acc.p;
-        c.inv_bitmap = e->b_bitmap.p; c.inv_list = e->b_list.p;
+        c.inv_bitmap = e->b_bitmap.p; c.inv_list = e->b_list.p; c.vinc = e->b_vinc.p;
         if (large) {
             hipLaunchKernelGGL(k_learn_large<T>, dim3(1), dim3(64), 0, e->stream, c, ev, lr);
             return;
@@ -574,6 +643,7 @@ int qe_env_create(qe_env** out, qe_engine* e, int64_t N, const qe_env_params* p)
     if (err == hipSuccess) err = env->term.ensure(un);
     if (err == hipSuccess) err = env->pred.ensure(un * 8);
     if (err == hipSuccess) err = env->aux.ensure(un);
+    if (err == hipSuccess) err = env->vinc.ensure(un);
     if (err == hipSuccess) err = env->bitmap.ensure((un + 31) / 32);
     if (err == hipSuccess) err = hipMemsetAsync(env->bitmap.p, 0, env->bitmap.cap * 4, e->stream);
     if (err != hipSuccess) {
@@ -590,7 +660,7 @@ int qe_env_destroy(qe_env* env) {
     (void)hipStreamSynchronize(env->e->stream);
     env->s.release(); env->a.release(); env->n.release(); env->list.release(); env->r.release();
     env->acc.release(); env->term.release(); env->pred.release(); env->aux.release();
-    env->bitmap.release(); env->masks.release();
+    env->bitmap.release(); env->masks.release(); env->vinc.release();
     delete env;
     return QE_OK;
 }

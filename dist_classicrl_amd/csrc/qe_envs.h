@@ -12,6 +12,7 @@ constexpr uint32_t C_REWARD = 0x9E3779B9u;
 constexpr uint32_t C_TERM = 0x85EBCA6Bu;
 constexpr uint32_t C_MASK = 0xA511E9B3u;
 constexpr uint32_t C_HOLE = 0x1B873593u;
+constexpr uint32_t C_START = 0x2545F491u;
 
 struct EnvCtx {
     // parameters
@@ -58,9 +59,11 @@ struct HostEnv {
 struct HashEnv {
     static __device__ __forceinline__ int32_t start_state(const EnvCtx& ev, int64_t agent,
                                                           uint32_t episode) {
-        const U4 x = philox4x32_10(ev.agent_offset + (uint32_t)agent, episode, 0u, STREAM_ENV,
-                                   ev.seed, 0u);
-        return (int32_t)mulhi32(x.x, (uint32_t)ev.S);
+        // two murmur finaliser rounds over (agent, episode, seed): ~15 ALU ops on the reset path of a
+        // latency-bound loop, where a Philox block would cost ~100
+        const uint32_t h = mix32(mix32((ev.agent_offset + (uint32_t)agent) ^ (ev.seed ^ C_START)) +
+                                 episode * 0x9E3779B9u);
+        return (int32_t)mulhi32(h, (uint32_t)ev.S);
     }
     static __device__ __forceinline__ uint32_t valid4(const EnvCtx& ev, int64_t, int32_t obs,
                                                       int sub) {

@@ -34,11 +34,12 @@ constexpr int FLAG_SELECT = 2;
 constexpr int FLAG_DETERMINISTIC = 4;  // greedy selection (evaluate_*: exploration_rate 0)
 constexpr int FLAG_PRED_FROM_TABLE = 8;  // qe_learn: Q[s,a] is not carried, read it
 constexpr int FLAG_ACCOUNT = 16;         // episode-return bookkeeping (rollouts; not qe_learn)
+constexpr int FLAG_NO_STAMPS = 32;       // persistent kernel: contention is tracked in LDS instead
 
 struct Ctrl {
     long long t_local;                   // vector step inside the current rollout call
     unsigned int inv_count;              // involved agents of the step being processed
-    unsigned int pad;
+    unsigned int error;                  // set by a kernel that had to give up (never expected)
     unsigned long long ep_count;         // episode-log entries written
     unsigned long long involved_total;   // statistics
 };
@@ -54,9 +55,10 @@ struct Ctx {
     int64_t S;
     int32_t A, ld, L, lshift;
     int64_t N;
-    uint32_t* stamps;       // [S][2] touch counters
+    unsigned long long* stamps;  // [S][2] touch counters: writers << 32 | readers
     uint32_t* inv_bitmap;   // ceil(N/32) words
     int32_t* inv_list;      // N
+    double* vinc;           // N: VEC-mode increments of involved agents
     Ctrl* ctrl;
     // agent state: pending transition (s, a, pred, r, term) and current observation n
     int32_t* s;
@@ -84,8 +86,17 @@ struct Ctx {
     long long dlog_base, dlog_cap;
 };
 
-__device__ __forceinline__ void touch(uint32_t* stamps, int64_t row, int par) {
-    atomicAdd(&stamps[2 * row + par], 1u);  // result unused -> non-returning global_atomic_add
+// Touch counters.  A row is CONTESTED in a step when two agents write it, or one writes it and a
+// different one reads it (each agent touches a row at most once per step: its read of row n is
+// dropped when n == s).  Rows that are only read by several agents are not contested.
+constexpr unsigned long long TOUCH_W = 1ull << 32, TOUCH_R = 1ull;
+__device__ __forceinline__ void touch(unsigned long long* stamps, int64_t row, int par,
+                                      unsigned long long kind) {
+    atomicAdd(&stamps[2 * row + par], kind);  // result unused -> non-returning global_atomic_add_x2
+}
+__device__ __forceinline__ bool contested(unsigned long long v) {
+    const uint32_t w = (uint32_t)(v >> 32), r = (uint32_t)v;
+    return w >= 2u || (w == 1u && r >= 1u);
 }
 
 template <typename T>
@@ -124,26 +135,60 @@ __device__ __forceinline__ void log_delta(const Ctx<T>& c, long long t, int64_t 
     }
 }
 
-// select(t1) + env.step(t1) + touches(t1) + write the new pending transition.  `row` holds Q[n].
+// select(t1) + env.step(t1) + touches(t1); the new pending transition is returned in registers.
+// `row` holds Q[n].  Every lane of the group evaluates the (pure-ALU) environment step; lane 0
+// registers the touches.
+template <typename T>
+struct Pending {
+    int32_t s, a, n;
+    T pred;
+    float r;
+    bool term;
+    uint32_t aux;
+};
+
+template <typename T, class Env, int LC = 0>
+__device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
+                                                   const Row4<T>& row, uint32_t valid, long long t1,
+                                                   int flags, const U4& x, Pending<T>& p) {
+    const bool explore = !(flags & FLAG_DETERMINISTIC) && (unsigned long long)x.x < c.thr[t1];
+    T picked;
+    const int act = select_action<LC>(row, valid, sub, c.L, explore, x.y, x.z, &picked);
+    const int32_t n = p.n;
+    const Transition tr = Env::step(ev, i, n, p.aux, act);
+    if (sub == 0) {
+        if (!(flags & FLAG_NO_STAMPS)) {
+            const int par1 = (int)(t1 & 1);
+            touch(c.stamps, n, par1, TOUCH_W);
+            if (tr.next_obs != n) touch(c.stamps, tr.next_obs, par1, TOUCH_R);
+        }
+        if (c.trace) c.trace[t1 * c.N + i] = act;
+    }
+    p.s = n; p.a = act; p.pred = picked; p.r = tr.reward; p.term = tr.terminated; p.n = tr.next_obs;
+}
+
+template <typename T, class Env, int LC = 0>
+__device__ __forceinline__ void advance_regs(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
+                                             const Row4<T>& row, uint32_t valid, long long t1, int flags,
+                                             Pending<T>& p) {
+    const unsigned long long step = c.step0 + (unsigned long long)t1;
+    const U4 x = philox4x32_10(c.agent_offset + (uint32_t)i, (uint32_t)step, (uint32_t)(step >> 32),
+                               STREAM_POLICY, c.seed_lo, c.seed_hi);
+    advance_with_draws<T, Env, LC>(c, ev, i, sub, row, valid, t1, flags, x, p);
+}
+
+// same, with the agent state kept in the global arrays (step-wise kernels)
 template <typename T, class Env>
 __device__ __forceinline__ void advance_agent(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
                                               int32_t n, Row4<T>& row, uint32_t valid, long long t1,
                                               int flags) {
-    const unsigned long long step = c.step0 + (unsigned long long)t1;
-    const U4 x = philox4x32_10(c.agent_offset + (uint32_t)i, (uint32_t)step, (uint32_t)(step >> 32),
-                               STREAM_POLICY, c.seed_lo, c.seed_hi);
-    const bool explore = !(flags & FLAG_DETERMINISTIC) && (unsigned long long)x.x < c.thr[t1];
-    T picked;
-    const int act = select_action(row, valid, sub, c.L, explore, x.y, x.z, &picked);
+    Pending<T> p;
+    p.n = n;
+    p.aux = c.aux[i];
+    advance_regs<T, Env>(c, ev, i, sub, row, valid, t1, flags, p);
     if (sub == 0) {
-        uint32_t aux = c.aux[i];
-        const Transition tr = Env::step(ev, i, n, aux, act);
-        const int par1 = (int)(t1 & 1);
-        touch(c.stamps, n, par1);
-        if (tr.next_obs != n) touch(c.stamps, tr.next_obs, par1);
-        c.s[i] = n; c.a[i] = act; c.pred[i] = picked; c.r[i] = tr.reward;
-        c.term[i] = tr.terminated ? 1 : 0; c.n[i] = tr.next_obs; c.aux[i] = aux;
-        if (c.trace) c.trace[t1 * c.N + i] = act;
+        c.s[i] = p.s; c.a[i] = p.a; c.pred[i] = p.pred; c.r[i] = p.r;
+        c.term[i] = p.term ? 1 : 0; c.n[i] = p.n; c.aux[i] = p.aux;
     }
 }
 
@@ -162,9 +207,9 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
     if (flags & FLAG_LEARN) {
         const int par = (int)(t & 1);
         const int32_t s = c.s[i];
-        const uint32_t cs = c.stamps[2 * (int64_t)s + par];
-        const uint32_t cn = c.stamps[2 * (int64_t)n + par];
-        if (cs > 1u || (n != s && cn > 1u)) {  // shared row: defer to the ordered path
+        const unsigned long long cs = c.stamps[2 * (int64_t)s + par];
+        const unsigned long long cn = c.stamps[2 * (int64_t)n + par];
+        if (contested(cs) || (n != s && contested(cn))) {  // shared row: defer to the ordered path
             if (sub == 0) {
                 atomicOr(&c.inv_bitmap[i >> 5], 1u << (i & 31));
                 atomicAdd(&c.ctrl->inv_count, 1u);
@@ -176,13 +221,13 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
         const bool term = c.term[i] != 0;
         const T m = row_max_valid(row, valid, c.L);
         if (sub == 0) {
-            c.stamps[2 * (int64_t)s + par] = 0u;
-            if (n != s) c.stamps[2 * (int64_t)n + par] = 0u;
+            c.stamps[2 * (int64_t)s + par] = 0ull;
+            if (n != s) c.stamps[2 * (int64_t)n + par] = 0ull;
         }
         const int64_t cell = (int64_t)s * c.ld + a;
         const T q0 = (flags & FLAG_PRED_FROM_TABLE) ? c.q[cell] : c.pred[i];
-        const T u = Td<T>::delta(q0, r, m, term, make_hyper(c, c.lr[t]), c.mode);
-        const T q1 = q0 + u;
+        T u;
+        const T q1 = Td<T>::apply(q0, r, m, term, make_hyper(c, c.lr[t]), c.mode, &u);
         if (sub == 0) {
             c.q[cell] = q1;
             log_delta(c, t, i, cell, u);
@@ -199,9 +244,10 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
 }
 
 // -------------------------------------------------------------------------------------------------
-// block-wide exclusive scan of one int per thread (SLOW_BLOCK threads); returns the block total.
+// block-wide exclusive scan of one int per thread (blockDim.x a multiple of 64, <= 1024).
 __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wave_sums) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = (int)(blockDim.x >> 6);
     int incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -211,7 +257,6 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wave_sums
     if (lane == 63) wave_sums[wave] = incl;
     __syncthreads();
     if (wave == 0) {
-        const int nw = SLOW_BLOCK / 64;
         int w = lane < nw ? wave_sums[lane] : 0;
         int wi = w;
 #pragma unroll
@@ -220,196 +265,553 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wave_sums
             if (lane >= off) wi += t;
         }
         if (lane < nw) wave_sums[lane] = wi - w;
-        if (lane == nw - 1) wave_sums[nw] = wi;
+        if (lane == nw - 1) wave_sums[16] = wi;
     }
     __syncthreads();
     const int res = wave_sums[wave] + incl - v;
-    *total = wave_sums[SLOW_BLOCK / 64];
+    *total = wave_sums[16];
     __syncthreads();
     return res;
 }
 
-// learn(t) for one involved agent with live (L1-bypassing) table accesses; all L lanes call it.
+// LDS working set of the ordered path (one workgroup); CAP = involved agents handled by the
+// dataflow rounds, 4 * CAP hash slots (>= 2 x the touches).
+template <int CAP>
+struct SlowLdsT {
+    static constexpr int kCap = CAP, kHash = 4 * CAP;
+    int scan[18];
+    int remaining;
+    int h_key[4 * CAP];
+    int h_head[4 * CAP];
+    int h_done[4 * CAP];
+    int t_next[2 * CAP];
+    short a_slot[2 * CAP];
+    short a_rank[2 * CAP];
+    unsigned char a_state[CAP];  // 0 = waiting, 1 = done, 2 = executed this round
+};
+
+// Inside the ordered path the table and the agent arrays are read and written by several waves of
+// ONE workgroup.  Plain accesses are used: conflicting accesses are always separated by
+// __syncthreads() (a workgroup-scope release/acquire), and all waves of a workgroup share their
+// CU's L1.  Only words updated by atomics elsewhere (the involved bitmap) are read L1-bypassing.
+template <typename T>
+struct LiveAgent {
+    int32_t s, a, n;
+    float r;
+    bool term;
+};
+template <typename T>
+__device__ __forceinline__ LiveAgent<T> live_agent(const Ctx<T>& c, int64_t i) {
+    LiveAgent<T> g;
+    g.s = c.s[i]; g.a = c.a[i]; g.n = c.n[i]; g.r = c.r[i]; g.term = c.term[i] != 0;
+    return g;
+}
+
+// learn(t) for one involved agent; all L lanes of a group call it.
 template <typename T, class Env>
 __device__ __forceinline__ void ordered_learn(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
                                               long long t) {
-    const int32_t s = c.s[i], a = c.a[i], n = c.n[i];
-    const float r = c.r[i];
-    const bool term = c.term[i] != 0;
+    const LiveAgent<T> g = live_agent(c, i);
     T m = 0;
-    if (!term) {
-        const Row4<T> row = load_row4_live(c.q, n, c.ld, sub);
-        m = row_max_valid(row, Env::valid4(ev, i, n, sub), c.L);
+    if (!g.term) {
+        const Row4<T> row = load_row4(c.q, g.n, c.ld, sub);
+        m = row_max_valid(row, Env::valid4(ev, i, g.n, sub), c.L);
     }
     if (sub == 0) {
-        const int64_t cell = (int64_t)s * c.ld + a;
-        const T q0 = load_live(c.q + cell);
-        const T u = Td<T>::delta(q0, r, m, term, make_hyper(c, c.lr[t]), 0);
-        store_live(c.q + cell, q0 + u);
+        const int64_t cell = (int64_t)g.s * c.ld + g.a;
+        const T q0 = c.q[cell];
+        T u;
+        c.q[cell] = Td<T>::apply(q0, g.r, m, g.term, make_hyper(c, c.lr[t]), 0, &u);
         log_delta(c, t, i, cell, u);
     }
 }
 
-template <typename T, class Env>
-__global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, int flags) {
-    __shared__ int sh_scan[SLOW_BLOCK / 64 + 2];
-    __shared__ int sh_remaining;
-    __shared__ int h_key[SLOW_HASH];
-    __shared__ int h_head[SLOW_HASH];
-    __shared__ int h_done[SLOW_HASH];
-    __shared__ int t_next[2 * SLOW_CAP];
-    __shared__ short a_slot[2 * SLOW_CAP];
-    __shared__ short a_rank[2 * SLOW_CAP];
-    __shared__ unsigned char a_state[SLOW_CAP];  // 0 = waiting, 1 = done, 2 = executed this round
-
-    const int tid = threadIdx.x;
-    const long long t = c.ctrl->t_local;
-    const int M = (int)c.ctrl->inv_count;
+// Ordered processing of the M involved agents of step t by ONE workgroup (all threads call it).
+// On return their transitions are learned, accounted (FLAG_ACCOUNT), their stamps cleared and --
+// with FLAG_SELECT -- their next transition (select(t+1), env.step(t+1), touches) is pending in the
+// global arrays.
+template <typename T, class Env, int CAP>
+__device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long long t, int M,
+                          SlowLdsT<CAP>& lds) {
+    constexpr int HASH = 4 * CAP;
+    const int tid = threadIdx.x, BS = (int)blockDim.x;
     const int L = c.L;
-    const int grp = tid >> c.lshift, sub = tid & (L - 1), ngrp = SLOW_BLOCK >> c.lshift;
+    const int grp = tid >> c.lshift, sub = tid & (L - 1), ngrp = BS >> c.lshift;
 
-    if (M > 0 && (flags & FLAG_LEARN)) {
-        // ---- ordered list of involved agents from the bitmap (ascending agent index) ----------
-        const int W = (int)((c.N + 31) >> 5);
-        int base = 0;
-        for (int w0 = 0; w0 < W; w0 += SLOW_BLOCK) {
-            const int w = w0 + tid;
-            uint32_t word = w < W ? c.inv_bitmap[w] : 0u;
-            int total;
-            int p = base + block_excl_scan(__popc(word), &total, sh_scan);
-            while (word) {
-                const int b = __ffs(word) - 1;
-                c.inv_list[p++] = w * 32 + b;
-                word &= word - 1u;
-            }
-            if (w < W) c.inv_bitmap[w] = 0u;
-            base += total;
+    // ---- ordered list of involved agents from the bitmap (ascending agent index) --------------
+    const int W = (int)((c.N + 31) >> 5);
+    int base = 0;
+    for (int w0 = 0; w0 < W; w0 += BS) {
+        const int w = w0 + tid;
+        uint32_t word = w < W ? load_live(c.inv_bitmap + w) : 0u;
+        int total;
+        int p = base + block_excl_scan(__popc(word), &total, lds.scan);
+        while (word) {
+            const int b = __ffs(word) - 1;
+            c.inv_list[p++] = w * 32 + b;
+            word &= word - 1u;
         }
-        __threadfence_block();
-        __syncthreads();
+        if (w < W) store_live(c.inv_bitmap + w, 0u);
+        base += total;
+    }
+    __syncthreads();
 
-        if (c.mode == 1) {
-            // ---- VEC: every involved agent reads the pre-step table, then colliding increments
-            // accumulate with atomicAdd (learn_vec / np.add.at, q_learning_optimal.py:235-250,889-891)
-            for (int p0 = 0; p0 < M; p0 += ngrp) {  // pass A: reads
-                const int pos = p0 + grp;
-                if (pos < M) {
-                    const int64_t i = load_live(c.inv_list + pos);
-                    const int32_t s = c.s[i], a = c.a[i], n = c.n[i];
-                    const bool term = c.term[i] != 0;
-                    const Row4<T> row = load_row4_live(c.q, n, c.ld, sub);
-                    const T m = row_max_valid(row, Env::valid4(ev, i, n, sub), L);
-                    if (sub == 0) {
-                        const T q0 = load_live(c.q + (int64_t)s * c.ld + a);
-                        c.pred[i] = Td<T>::delta(q0, c.r[i], m, term, make_hyper(c, c.lr[t]), 1);
-                    }
+    if (c.mode == 1) {
+        // ---- VEC (learn_vec / np.add.at, q_learning_optimal.py:235-250,889-891): every involved
+        // agent forms its increment from the pre-step table; increments that collide on a cell
+        // are then accumulated in agent order by the first of them (exactly np.add.at), or with
+        // atomicAdd when there are too many involved agents to pair them up in LDS.
+        double* inc = c.vinc;
+        uint32_t* cells = reinterpret_cast<uint32_t*>(lds.t_next);
+        for (int p0 = 0; p0 < M; p0 += ngrp) {  // pass A: reads
+            const int pos = p0 + grp;
+            if (pos < M) {
+                const int64_t i = c.inv_list[pos];
+                const LiveAgent<T> g = live_agent(c, i);
+                const Row4<T> row = load_row4(c.q, g.n, c.ld, sub);
+                const T m = row_max_valid(row, Env::valid4(ev, i, g.n, sub), L);
+                if (sub == 0) {
+                    const int64_t cell = (int64_t)g.s * c.ld + g.a;
+                    const T q0 = c.q[cell];
+                    const Hyper h = make_hyper(c, c.lr[t]);
+                    double u;
+                    if constexpr (sizeof(T) == 4) u = Td<float>::vec_inc(q0, g.r, m, g.term, h);
+                    else u = Td<double>::delta(q0, g.r, m, g.term, h);
+                    inc[i] = u;
+                    if (pos < 2 * CAP) cells[pos] = (uint32_t)cell;
+                    log_delta(c, t, i, cell, (T)u);
                 }
             }
-            __threadfence_block();
-            __syncthreads();
-            for (int pos = tid; pos < M; pos += SLOW_BLOCK) {  // pass B: scatter-add
-                const int64_t i = load_live(c.inv_list + pos);
-                const int64_t cell = (int64_t)c.s[i] * c.ld + c.a[i];
-                const T u = load_live(c.pred + i);
-                atomicAdd(c.q + cell, u);
-                log_delta(c, t, i, cell, u);
-            }
-        } else if (M <= SLOW_CAP) {
-            // ---- ITER: dataflow rounds; per shared row, touchers run in agent order -------------
-            for (int k = tid; k < SLOW_HASH; k += SLOW_BLOCK) { h_key[k] = -1; h_head[k] = -1; h_done[k] = 0; }
-            if (tid == 0) sh_remaining = M;
-            __syncthreads();
-            for (int id = tid; id < 2 * M; id += SLOW_BLOCK) {
-                const int pos = id >> 1;
-                const int64_t i = load_live(c.inv_list + pos);
-                const int32_t s = c.s[i], n = c.n[i];
-                const bool need = (id & 1) == 0 || (c.term[i] == 0 && n != s);
-                int slot = -1;
-                if (need) {
-                    const int32_t rowid = (id & 1) ? n : s;
-                    int h = (int)(mix32((uint32_t)rowid) & (SLOW_HASH - 1));
-                    for (;;) {
-                        const int old = atomicCAS(&h_key[h], -1, rowid);
-                        if (old == -1 || old == rowid) break;
-                        h = (h + 1) & (SLOW_HASH - 1);
-                    }
-                    slot = h;
-                    t_next[id] = atomicExch(&h_head[h], id);
-                }
-                a_slot[id] = (short)slot;
-                if ((id & 1) == 0) a_state[pos] = 0;
-            }
-            __syncthreads();
-            for (int id = tid; id < 2 * M; id += SLOW_BLOCK) {  // rank = lower-indexed touchers
-                const int slot = a_slot[id];
-                int rank = 0;
-                if (slot >= 0)
-                    for (int o = h_head[slot]; o >= 0; o = t_next[o]) rank += (o >> 1) < (id >> 1);
-                a_rank[id] = (short)rank;
-            }
-            __syncthreads();
-            while (sh_remaining > 0) {
-                for (int p0 = 0; p0 < M; p0 += ngrp) {
-                    const int pos = p0 + grp;
-                    bool go = false;
-                    if (pos < M && a_state[pos] == 0) {
-                        const int ss = a_slot[2 * pos], sn = a_slot[2 * pos + 1];
-                        go = h_done[ss] == a_rank[2 * pos] && (sn < 0 || h_done[sn] == a_rank[2 * pos + 1]);
-                    }
-                    if (go) {
-                        ordered_learn<T, Env>(c, ev, load_live(c.inv_list + pos), sub, t);
-                        if (sub == 0) a_state[pos] = 2;
-                    }
-                }
-                __threadfence_block();
-                __syncthreads();
-                for (int pos = tid; pos < M; pos += SLOW_BLOCK) {
-                    if (a_state[pos] == 2) {
-                        a_state[pos] = 1;
-                        atomicAdd(&h_done[a_slot[2 * pos]], 1);
-                        if (a_slot[2 * pos + 1] >= 0) atomicAdd(&h_done[a_slot[2 * pos + 1]], 1);
-                        atomicSub(&sh_remaining, 1);
-                    }
-                }
-                __syncthreads();
+        }
+        __syncthreads();
+        if (M <= 2 * CAP) {
+            for (int pos = tid; pos < M; pos += BS) {  // pass B: ordered accumulate
+                const uint32_t cell = cells[pos];
+                bool leader = true;
+                for (int j = 0; j < pos && leader; ++j) leader = cells[j] != cell;
+                if (!leader) continue;
+                T q = c.q[cell];
+                for (int j = pos; j < M; ++j)
+                    if (cells[j] == cell) q = (T)((double)q + inc[c.inv_list[j]]);
+                c.q[cell] = q;
             }
         } else {
-            // ---- ITER, too many involved agents for LDS: strictly sequential on one wave ----------
-            if (tid < 64) {
-                for (int pos = 0; pos < M; ++pos) {
-                    if (tid < L) ordered_learn<T, Env>(c, ev, load_live(c.inv_list + pos), tid, t);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                }
+            for (int pos = tid; pos < M; pos += BS) {  // pass B: scatter-add
+                const int64_t i = c.inv_list[pos];
+                atomicAdd(c.q + (int64_t)c.s[i] * c.ld + c.a[i], (T)inc[i]);
             }
         }
-        __threadfence_block();
+    } else if (M <= CAP) {
+        // ---- ITER: dataflow rounds; per shared row, touchers run in agent order ---------------
+        for (int k = tid; k < HASH; k += BS) { lds.h_key[k] = -1; lds.h_head[k] = -1; lds.h_done[k] = 0; }
+        if (tid == 0) lds.remaining = M;
         __syncthreads();
-
-        // ---- bookkeeping, stamp clean-up, then select(t+1) + env.step(t+1) for involved agents ---
-        const int par = (int)(t & 1);
-        for (int pos = tid; pos < M; pos += SLOW_BLOCK) {
-            const int64_t i = load_live(c.inv_list + pos);
-            if (flags & FLAG_ACCOUNT) account(c, t, i, c.r[i], c.term[i] != 0);
-            store_live(c.stamps + 2 * (int64_t)c.s[i] + par, 0u);
-            store_live(c.stamps + 2 * (int64_t)c.n[i] + par, 0u);
+        for (int id = tid; id < 2 * M; id += BS) {
+            const int pos = id >> 1;
+            const int64_t i = c.inv_list[pos];
+            const LiveAgent<T> g = live_agent(c, i);
+            const bool need = (id & 1) == 0 || (!g.term && g.n != g.s);
+            int slot = -1;
+            if (need) {
+                const int32_t rowid = (id & 1) ? g.n : g.s;
+                int h = (int)(mix32((uint32_t)rowid) & (HASH - 1));
+                for (;;) {
+                    const int old = atomicCAS(&lds.h_key[h], -1, rowid);
+                    if (old == -1 || old == rowid) break;
+                    h = (h + 1) & (HASH - 1);
+                }
+                slot = h;
+                lds.t_next[id] = atomicExch(&lds.h_head[h], id);
+            }
+            lds.a_slot[id] = (short)slot;
+            if ((id & 1) == 0) lds.a_state[pos] = 0;
         }
-        if (flags & FLAG_SELECT) {
+        __syncthreads();
+        for (int id = tid; id < 2 * M; id += BS) {  // rank = lower-indexed touchers of the row
+            const int slot = lds.a_slot[id];
+            int rank = 0;
+            if (slot >= 0)
+                for (int o = lds.h_head[slot]; o >= 0; o = lds.t_next[o]) rank += (o >> 1) < (id >> 1);
+            lds.a_rank[id] = (short)rank;
+        }
+        __syncthreads();
+        // every round retires at least the lowest-indexed waiting agent, so M rounds always suffice;
+        // the guard only keeps a logic error from hanging the GPU (reported through ctrl->error).
+        int rounds = 0;
+        while (lds.remaining > 0 && rounds++ <= M) {
             for (int p0 = 0; p0 < M; p0 += ngrp) {
                 const int pos = p0 + grp;
-                if (pos < M) {
-                    const int64_t i = load_live(c.inv_list + pos);
-                    const int32_t n = c.n[i];
-                    Row4<T> row = load_row4_live(c.q, n, c.ld, sub);
-                    advance_agent<T, Env>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
+                bool go = false;
+                if (pos < M && lds.a_state[pos] == 0) {
+                    const int ss = lds.a_slot[2 * pos], sn = lds.a_slot[2 * pos + 1];
+                    go = lds.h_done[ss] == lds.a_rank[2 * pos] &&
+                         (sn < 0 || lds.h_done[sn] == lds.a_rank[2 * pos + 1]);
                 }
+                if (go) {
+                    ordered_learn<T, Env>(c, ev, c.inv_list[pos], sub, t);
+                    if (sub == 0) lds.a_state[pos] = 2;
+                }
+            }
+            __syncthreads();
+            for (int pos = tid; pos < M; pos += BS) {
+                if (lds.a_state[pos] == 2) {
+                    lds.a_state[pos] = 1;
+                    atomicAdd(&lds.h_done[lds.a_slot[2 * pos]], 1);
+                    if (lds.a_slot[2 * pos + 1] >= 0) atomicAdd(&lds.h_done[lds.a_slot[2 * pos + 1]], 1);
+                    atomicSub(&lds.remaining, 1);
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0 && lds.remaining > 0) c.ctrl->error = 1u;
+    } else {
+        // ---- ITER, too many involved agents for LDS: strictly sequential on one wave ----------
+        if (tid < 64) {
+            for (int pos = 0; pos < M; ++pos) {
+                if (tid < L) ordered_learn<T, Env>(c, ev, c.inv_list[pos], tid, t);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
         }
     }
     __syncthreads();
-    if (tid == 0) {
+
+    // ---- bookkeeping, stamp clean-up, then select(t+1) + env.step(t+1) for involved agents -----
+    const int par = (int)(t & 1);
+    for (int pos = tid; pos < M; pos += BS) {
+        const int64_t i = c.inv_list[pos];
+        const LiveAgent<T> g = live_agent(c, i);
+        if (flags & FLAG_ACCOUNT) account(c, t, i, g.r, g.term);
+        if (!(flags & FLAG_NO_STAMPS)) {
+            c.stamps[2 * (int64_t)g.s + par] = 0ull;
+            c.stamps[2 * (int64_t)g.n + par] = 0ull;
+        }
+    }
+    if (flags & FLAG_SELECT) {
+        for (int p0 = 0; p0 < M; p0 += ngrp) {
+            const int pos = p0 + grp;
+            if (pos < M) {
+                const int64_t i = c.inv_list[pos];
+                const int32_t n = c.n[i];
+                Row4<T> row = load_row4(c.q, n, c.ld, sub);
+                advance_agent<T, Env>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
+            }
+        }
+    }
+}
+
+using SlowLds = SlowLdsT<SLOW_CAP>;
+
+template <typename T, class Env>
+__global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, int flags) {
+    __shared__ SlowLds lds;
+    const long long t = c.ctrl->t_local;
+    const int M = (int)c.ctrl->inv_count;
+    if (M > 0 && (flags & FLAG_LEARN)) slow_body<T, Env, SLOW_CAP>(c, ev, flags, t, M, lds);
+    __syncthreads();
+    if (threadIdx.x == 0) {
         c.ctrl->involved_total += (unsigned long long)M;
         c.ctrl->inv_count = 0u;
         if (flags & FLAG_LEARN) c.ctrl->t_local = t + 1;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Persistent rollout: when all agents fit one workgroup (<= 512 agents, <= 1024 lanes) the whole
+// `steps`-step loop runs in ONE launch on one CU.
+//   * agent state and the pending transition stay in registers across steps;
+//   * the step boundary is ONE workgroup barrier in a quiet step (no kernel boundary);
+//   * row contention is tracked in three rotating LDS hash tables (row -> writers<<16 | readers,
+//     lowest toucher index) instead of the global stamps: no global atomics on the critical path
+//     (measured on MI355X: a global atomic + completion wait 0.4-0.7 us, an LDS atomic ~0.05 us);
+//   * the row gather is issued right after the barrier and the Philox draws of the next selection
+//     are computed while it is in flight;
+//   * the episode log is staged in LDS and flushed in bulk (this workgroup owns ctrl->ep_count);
+//   * the lane-group width is a template parameter, so reductions lower to DPP moves.
+// Shared rows: on every contested row the lowest-indexed toucher proceeds at once (its inputs
+// cannot have been modified yet), the others run afterwards in index order -- in place, in short
+// barrier-separated rounds, when every contested row has exactly two touchers (the common case),
+// through slow_body otherwise.  An agent whose next-state row is written by another agent in this
+// step re-reads that row after all updates before selecting its next action.
+constexpr int PERSIST_MAX_LANES = 1024;
+constexpr int PERSIST_MAX_AGENTS = 512;
+constexpr int CT_SLOTS = 2048;      // contention table slots (>= 2 x touches per step)
+constexpr int EP_STAGE = 2048;      // staged episode-log entries
+
+struct PersistLds {
+    SlowLdsT<PERSIST_MAX_AGENTS> slow;
+    int ct_key[3][CT_SLOTS];
+    unsigned ct_cnt[3][CT_SLOTS];
+    int ct_min[3][CT_SLOTS];
+    unsigned long long ep_key[EP_STAGE];
+    float ep_ret[EP_STAGE];
+    unsigned char pending[PERSIST_MAX_AGENTS];  // 1 while an agent's deferred update is outstanding
+    unsigned busy[3];     // step t: some row has more than one toucher
+    unsigned ep_n;
+    unsigned n_def;       // agents whose update is deferred in this step
+    unsigned n_rem;       // ... and not yet executed
+    unsigned complex_;    // a contested row has more than two touchers
+};
+
+__device__ __forceinline__ int ct_insert(PersistLds& l, int tb, int32_t row, unsigned kind, int agent) {
+    int h = (int)(mix32((uint32_t)row) & (CT_SLOTS - 1));
+    for (;;) {
+        const int old = atomicCAS(&l.ct_key[tb][h], -1, row);
+        if (old == -1 || old == row) break;
+        h = (h + 1) & (CT_SLOTS - 1);
+    }
+    if (atomicAdd(&l.ct_cnt[tb][h], kind) != 0u) l.busy[tb] = 1u;
+    atomicMin(&l.ct_min[tb][h], agent);
+    return h;
+}
+
+#ifdef QE_STAMPS
+#define QE_STAMP(k) do { const long long _n = wall_clock64(); stamp_sum[k] += _n - stamp_last; stamp_last = _n; } while (0)
+#else
+#define QE_STAMP(k) do { } while (0)
+#endif
+
+template <typename T, class Env, int LC>
+__global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev, long long steps, int flags) {
+    __shared__ PersistLds lds;
+#ifdef QE_STAMPS
+    long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_last = wall_clock64();
+#endif
+    const int tid = threadIdx.x;
+    const int L = LC ? LC : c.L;
+    const int i = tid >> c.lshift;
+    const int sub = tid & (L - 1);
+    const bool active = i < c.N;
+    const int ii = active ? i : 0;
+    const bool lead = active && sub == 0;
+    const int sflags = flags | FLAG_NO_STAMPS;
+    Pending<T> p;
+    p.n = c.n[ii];
+    p.aux = c.aux[ii];
+    p.s = 0; p.a = 0; p.pred = 0; p.r = 0.0f; p.term = false;
+    float acc = c.acc[ii];
+    unsigned long long deferred_total = 0, ep_base = 0;
+    // table slots of steps t-1 / t-2.  Lane 0 of a group owns the row-s slot; the row-n slot is owned
+    // by lane 1 (slot) when the group has two or more lanes, by lane 0 (slot2) otherwise.
+    int cur_slot = -1, prev_slot = -1, cur_slot2 = -1, prev_slot2 = -1;
+    const int flush_every = EP_STAGE / 2 / (int)c.N > 0 ? EP_STAGE / 2 / (int)c.N : 1;
+    int flush_in = flush_every;
+    for (int k = tid; k < 3 * CT_SLOTS; k += (int)blockDim.x) {
+        (&lds.ct_key[0][0])[k] = -1;
+        (&lds.ct_cnt[0][0])[k] = 0u;
+        (&lds.ct_min[0][0])[k] = 0x7FFFFFFF;
+    }
+    for (int k = tid; k < PERSIST_MAX_AGENTS; k += (int)blockDim.x) lds.pending[k] = 0;
+    if (tid == 0) {
+        lds.ep_n = 0u; lds.n_def = 0u; lds.n_rem = 0u; lds.complex_ = 0u;
+        lds.busy[0] = lds.busy[1] = lds.busy[2] = 0u;
+    }
+    {   // select(0), env.step(0)
+        const Row4<T> row = load_row4(c.q, p.n, c.ld, sub);
+        if (active) advance_regs<T, Env, LC>(c, ev, i, sub, row, Env::valid4(ev, i, p.n, sub), 0, sflags, p);
+    }
+    __syncthreads();
+    int tb = 0;  // t % 3
+    for (long long t = 0; t < steps; ++t) {
+        const bool last = t + 1 == steps;
+        const int tb_old = tb == 2 ? 0 : tb + 1;  // (t - 2) % 3 == (t + 1) % 3: retired two barriers ago
+        QE_STAMP(7);
+        // ---- register this step's touches (W(s), R(n)); retire the entries of step t-2 ---------
+        // lane 0 of the group handles row s, lane 1 (when the group has one) row n: the two chains of
+        // dependent LDS atomics run side by side.
+        const bool two = LC != 1 && L > 1;
+        {
+            const bool mine = active && (sub == 0 || (two && sub == 1));
+            if (mine) {
+                const bool second = two ? sub == 1 : false;  // this lane's job: row n (else row s)
+                // before the rotation `prev_slot` is my slot of step t-2, which lives in table tb_old
+                if (prev_slot >= 0) {
+                    lds.ct_key[tb_old][prev_slot] = -1; lds.ct_cnt[tb_old][prev_slot] = 0u;
+                    lds.ct_min[tb_old][prev_slot] = 0x7FFFFFFF;
+                }
+                if (!two && prev_slot2 >= 0) {
+                    lds.ct_key[tb_old][prev_slot2] = -1; lds.ct_cnt[tb_old][prev_slot2] = 0u;
+                    lds.ct_min[tb_old][prev_slot2] = 0x7FFFFFFF;
+                }
+                prev_slot = cur_slot; prev_slot2 = cur_slot2;
+                const bool skip = second && p.n == p.s;
+                cur_slot = skip ? -1 : ct_insert(lds, tb, second ? p.n : p.s, second ? 1u : 1u << 16, i);
+                cur_slot2 = (!two && p.n != p.s) ? ct_insert(lds, tb, p.n, 1u, i) : -1;
+            }
+        }
+        if (tid == 0) lds.busy[tb_old] = 0u;
+        QE_STAMP(0);
+        __syncthreads();  // every table write of step t-1 is complete; touches of step t are in
+        QE_STAMP(1);
+        const bool busy = lds.busy[tb] != 0u;
+        Row4<T> row = load_row4(c.q, p.n, c.ld, sub);  // the one row gather of a quiet step
+        const uint32_t valid = Env::valid4(ev, ii, p.n, sub);
+        // ---- classification (only when some row has several touchers) ---------------------------
+        int cls = 3;  // bit0: update now, bit1: select now
+        int pred_s = -1, pred_n = -1;
+        if (busy) {
+            // row-n facts live on lane 1 of the group (lane 0 when the group is a single lane)
+            unsigned cn = 0u;
+            int mn = 0x7FFFFFFF, has_n = 0;
+            {
+                const int ns = two ? cur_slot : cur_slot2;
+                if (active && (two ? sub == 1 : sub == 0) && ns >= 0) {
+                    cn = lds.ct_cnt[tb][ns]; mn = lds.ct_min[tb][ns]; has_n = 1;
+                }
+            }
+            if (two) { cn = __shfl(cn, 1, L); mn = __shfl(mn, 1, L); has_n = __shfl(has_n, 1, L); }
+            if (lead) {
+                const unsigned cs = lds.ct_cnt[tb][cur_slot];
+                const int ms = lds.ct_min[tb][cur_slot];
+                const unsigned w_s = cs >> 16, tot_s = w_s + (cs & 0xFFFFu);
+                const unsigned w_n = cn >> 16, tot_n = w_n + (cn & 0xFFFFu);
+                bool now = true, sel = true, cx = false;
+                if (c.mode == 1) {
+                    // VEC (learn_vec): every toucher of a row that is written AND shared reads the
+                    // pre-step table, so all of them go through the batch path together
+                    const bool shared = w_s >= 2u || (w_s == 1u && tot_s >= 2u) || (has_n && w_n >= 1u && tot_n >= 2u);
+                    if (shared) { now = false; cx = true; }
+                    sel = !(has_n ? w_n > 0u : w_s > 1u);
+                } else {
+                    if (tot_s > 1u && ms < i) { now = false; pred_s = ms; cx |= tot_s > 2u; }
+                    if (has_n) {
+                        if (w_n > 0u) {
+                            sel = false;  // someone writes the row my next action is chosen from
+                            if (!p.term && mn < i) { now = false; pred_n = mn; cx |= tot_n > 2u; }
+                        }
+                    } else if (w_s > 1u) {
+                        sel = false;  // n == s and another agent writes this row too
+                    }
+                }
+                cls = (now ? 1 : 0) | (sel ? 2 : 0);
+                if (!now) {
+                    lds.pending[i] = 1;
+                    atomicAdd(&lds.n_def, 1u);
+                    if (cx) lds.complex_ = 1u;
+                }
+            }
+            if (LC != 1) cls = __shfl(cls, 0, L);
+        }
+        QE_STAMP(2);
+        // ---- Philox draws of select(t+1): independent of memory, computed under the row gather ---
+        const unsigned long long step1 = c.step0 + (unsigned long long)(t + 1);
+        const U4 x = philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)step1, (uint32_t)(step1 >> 32),
+                                   STREAM_POLICY, c.seed_lo, c.seed_hi);
+        const float r_t = p.r;
+        const bool term_t = p.term;
+        QE_STAMP(3);
+        // ---- update of transition t for agents that may go now ----------------------------------
+        if (active && (cls & 1)) {
+            const T m = row_max_valid<LC>(row, valid, L);
+            const int64_t cell = (int64_t)p.s * c.ld + p.a;
+            T u;
+            const T q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, c.lr[t]), c.mode, &u);
+            if (sub == 0) {
+                c.q[cell] = q1;
+                log_delta(c, t, i, cell, u);
+            }
+            if (p.n == p.s && (p.a >> 2) == sub) {
+                const int j = p.a & 3;
+                if (j == 0) row.v[0] = q1; else if (j == 1) row.v[1] = q1;
+                else if (j == 2) row.v[2] = q1; else row.v[3] = q1;
+            }
+        }
+        if (active) {  // base_runtime.py:212,218-221 for transition t
+            acc += r_t;
+            if (term_t) {
+                if (sub == 0 && (flags & FLAG_ACCOUNT)) {
+                    const unsigned k = atomicAdd(&lds.ep_n, 1u);
+                    lds.ep_key[k] = ((unsigned long long)t << 32) | (unsigned long long)i;
+                    lds.ep_ret[k] = acc;
+                }
+                acc = 0.0f;
+            }
+        }
+        QE_STAMP(4);
+        if (active && cls == 3 && !last) {
+            advance_with_draws<T, Env, LC>(c, ev, i, sub, row, valid, t + 1, sflags, x, p);
+        }
+        QE_STAMP(5);
+
+        if (busy) {
+            // ---- extended step: ordered updates of the deferred agents, then late selections -----
+            __syncthreads();
+            const int n_def = (int)lds.n_def;
+            if (n_def > 0) {
+                deferred_total += (unsigned long long)n_def;
+                if (lds.complex_) {
+                    // general case: hand the deferred transitions to slow_body through the arrays
+                    if (lead && !(cls & 1)) {
+                        c.s[i] = p.s; c.a[i] = p.a; c.pred[i] = p.pred; c.r[i] = p.r;
+                        c.term[i] = p.term ? 1 : 0; c.n[i] = p.n; c.aux[i] = p.aux;
+                        atomicOr(&c.inv_bitmap[i >> 5], 1u << (i & 31));
+                        lds.pending[i] = 0;
+                    }
+                    __syncthreads();
+                    slow_body<T, Env, PERSIST_MAX_AGENTS>(c, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
+                    __syncthreads();
+                } else {
+                    if (tid == 0) lds.n_rem = (unsigned)n_def;
+                    __syncthreads();
+                    bool mine = active && !(cls & 1);
+                    if (LC != 1) { pred_s = __shfl(pred_s, 0, L); pred_n = __shfl(pred_n, 0, L); }
+                    int rounds = 0;
+                    while (lds.n_rem > 0u && rounds++ <= n_def) {
+                        const bool go = mine && (pred_s < 0 || lds.pending[pred_s] == 0) &&
+                                        (pred_n < 0 || lds.pending[pred_n] == 0);
+                        __syncthreads();  // everyone has sampled the flags of this round
+                        if (go) {
+                            T m = 0;
+                            if (!p.term) {
+                                const Row4<T> fresh = load_row4(c.q, p.n, c.ld, sub);
+                                m = row_max_valid<LC>(fresh, valid, L);
+                            }
+                            if (sub == 0) {
+                                const int64_t cell = (int64_t)p.s * c.ld + p.a;
+                                const T q0 = c.q[cell];
+                                T u;
+                                c.q[cell] = Td<T>::apply(q0, p.r, m, p.term, make_hyper(c, c.lr[t]), 0, &u);
+                                log_delta(c, t, i, cell, u);
+                                lds.pending[i] = 0;
+                                atomicSub(&lds.n_rem, 1u);
+                            }
+                            mine = false;
+                        }
+                        __syncthreads();  // this round's table writes are complete and visible
+                    }
+                    if (tid == 0 && lds.n_rem > 0u) c.ctrl->error = 2u;
+                }
+            }
+            // every update of step t is in the table: late selections read their row again
+            if (active && cls != 3 && !last) {
+                const Row4<T> fresh = load_row4(c.q, p.n, c.ld, sub);
+                advance_with_draws<T, Env, LC>(c, ev, i, sub, fresh, valid, t + 1, sflags, x, p);
+            }
+            if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }
+        }
+        // ---- bulk flush of the staged episode log (uniform, data-independent decision) ----------
+        if (--flush_in == 0 || last) {  // at most flush_every * N <= EP_STAGE / 2 entries staged
+            flush_in = flush_every;
+            __syncthreads();
+            const unsigned staged = lds.ep_n;
+            for (unsigned k = tid; k < staged; k += blockDim.x) {
+                const unsigned long long pos = ep_base + k;
+                if ((long long)pos < c.ep_cap) { c.ep_key[pos] = lds.ep_key[k]; c.ep_ret[pos] = lds.ep_ret[k]; }
+            }
+            ep_base += staged;
+            __syncthreads();
+            if (tid == 0) lds.ep_n = 0u;
+        }
+        tb = tb == 2 ? 0 : tb + 1;
+        QE_STAMP(6);
+    }
+#ifdef QE_STAMPS
+    if (tid == 0 && c.vinc) for (int k = 0; k < 8; ++k) c.vinc[k] = (double)stamp_sum[k];
+#endif
+    if (lead) { c.n[i] = p.n; c.aux[i] = p.aux; c.acc[i] = acc; }
+    if (tid == 0) {
+        c.ctrl->involved_total += deferred_total;
+        c.ctrl->ep_count += ep_base;
     }
 }
 
@@ -512,7 +914,8 @@ __global__ __launch_bounds__(64) void k_learn_large(Ctx<T> c, EnvCtx ev, double 
     const int lane = threadIdx.x;
     const uint32_t* mbase = ev.masked ? ev.maskbits : nullptr;
     const Hyper h = make_hyper(c, lr);
-    if (c.mode == 1) {  // VEC: all increments from the pre-step table, then apply in index order
+    if (c.mode == 1) {  // VEC: all increments from the pre-step table, then np.add.at in index order
+        double* inc = c.vinc;
         for (int64_t i = 0; i < c.N; ++i) {
             const T* row = c.q + (int64_t)c.n[i] * c.ld;
             const uint32_t* mw = mbase ? mbase + i * ev.n_words : nullptr;
@@ -520,13 +923,18 @@ __global__ __launch_bounds__(64) void k_learn_large(Ctx<T> c, EnvCtx ev, double 
             for (int col = lane; col < c.A; col += 64)
                 if (!mw || ((mw[col >> 5] >> (col & 31)) & 1u)) m = row[col] > m ? row[col] : m;
             m = group_max(m, 64);
-            if (lane == 0)
-                c.pred[i] = Td<T>::delta(c.q[(int64_t)c.s[i] * c.ld + c.a[i]], c.r[i], m,
-                                         c.term[i] != 0, h, 1);
+            if (lane == 0) {
+                const T q0 = c.q[(int64_t)c.s[i] * c.ld + c.a[i]];
+                if constexpr (sizeof(T) == 4) inc[i] = Td<float>::vec_inc(q0, c.r[i], m, c.term[i] != 0, h);
+                else inc[i] = Td<double>::delta(q0, c.r[i], m, c.term[i] != 0, h);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (lane == 0)
-            for (int64_t i = 0; i < c.N; ++i) c.q[(int64_t)c.s[i] * c.ld + c.a[i]] += c.pred[i];
+            for (int64_t i = 0; i < c.N; ++i) {
+                T* cell = c.q + (int64_t)c.s[i] * c.ld + c.a[i];
+                *cell = (T)((double)*cell + inc[i]);
+            }
         return;
     }
     for (int64_t i = 0; i < c.N; ++i) {
@@ -546,7 +954,8 @@ __global__ __launch_bounds__(64) void k_learn_large(Ctx<T> c, EnvCtx ev, double 
         if (lane == 0) {
             T* cell = c.q + (int64_t)c.s[i] * c.ld + c.a[i];
             const T q0 = load_live(cell);
-            store_live(cell, q0 + Td<T>::delta(q0, c.r[i], m, term, h, 0));
+            T u;
+            store_live(cell, Td<T>::apply(q0, c.r[i], m, term, h, 0, &u));
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
@@ -558,8 +967,8 @@ __global__ void k_touch_batch(Ctx<T> c) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.N) return;
     const int32_t s = c.s[i], n = c.n[i];
-    touch(c.stamps, s, 0);
-    if (n != s) touch(c.stamps, n, 0);
+    touch(c.stamps, s, 0, TOUCH_W);
+    if (n != s) touch(c.stamps, n, 0, TOUCH_R);
 }
 
 // ---- environments driven from the host ----------------------------------------------------------

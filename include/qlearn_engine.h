@@ -75,6 +75,9 @@ typedef struct qe_rollout_stats {
     int64_t episodes;        /* episodes that ended during this rollout */
     int64_t involved;        /* agent-steps that went through the ordered (contested) path */
     int64_t episodes_dropped; /* episode-log overflow (0 unless capacity was exceeded) */
+    double dominant_ms;      /* summed HIP-event time of the sampled dominant-kernel launches */
+    int64_t dominant_launches; /* how many launches were sampled (<= 256, spread over the call) */
+    int64_t dominant_env_steps; /* env-steps (agent x vector step) those sampled launches processed */
 } qe_rollout_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -88,6 +91,10 @@ int qe_destroy(qe_engine* e);
 int qe_synchronize(qe_engine* e);
 /* Use the caller's HIP stream (hipStream_t as void*) instead of the engine's own. */
 int qe_set_stream(qe_engine* e, void* hip_stream);
+/* Tuning knobs (never change results).  QE_OPT_ROLLOUT_PATH: 0 = automatic, 1 = one kernel pair per
+ * vector step, 2 = persistent single-workgroup kernel (needs num_agents * lanes_per_row <= 1024). */
+enum qe_option { QE_OPT_ROLLOUT_PATH = 0 };
+int qe_set_option(qe_engine* e, int32_t option, int64_t value);
 
 /* ---- Q-table I/O ----------------------------------------------------------------------------
  * q_table property / save (q_learning_optimal.py:96, 252-261), parallel_runtime.py:70-77,171-176

@@ -16,12 +16,13 @@ from __future__ import annotations
 
 import numpy as np
 
-from .draws import STREAM_ENV, mix32, mulhi32, philox4x32
+from .draws import mix32, mulhi32
 
 C_REWARD = 0x9E3779B9
 C_TERM = 0x85EBCA6B
 C_MASK = 0xA511E9B3
 C_HOLE = 0x1B873593
+C_START = 0x2545F491
 
 
 class _VecEnvBase:
@@ -44,7 +45,7 @@ class HashTabularEnv(_VecEnvBase):
 
     reward      = (mix32(s' ^ C_REWARD ^ seed) >> 8) * 2**-24                (float32 exact)
     terminated  = (mix32(s' ^ C_TERM ^ seed) & 0xff) < p_term_256
-    start state = philox(key=seed; agent, episode, 0, STREAM_ENV)[0] * S >> 32
+    start state = mix32(mix32(agent ^ seed ^ C_START) + episode * 0x9E3779B9) * S >> 32
     mask word k = mix32((s * n_words + k) ^ seed ^ C_MASK); action 0 always valid
     """
 
@@ -61,8 +62,9 @@ class HashTabularEnv(_VecEnvBase):
         self.episode = np.zeros(self.num_agents, dtype=np.uint32)
 
     def _start_states(self, episode):
-        x0 = philox4x32(self.agent_ids, episode, 0, STREAM_ENV, self.seed, 0)[0]
-        return mulhi32(x0, self.state_size).astype(np.int32)
+        inner = mix32(self.agent_ids ^ np.uint32(self.seed ^ C_START)).astype(np.uint64)
+        h = mix32((inner + np.asarray(episode, dtype=np.uint64) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF))
+        return mulhi32(h, self.state_size).astype(np.int32)
 
     def action_masks(self, obs):
         n_words = (self.action_size + 31) // 32
