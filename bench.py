@@ -105,7 +105,8 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with a single rank)
+    if use_dist:
         import torch
         import torch.distributed as dist
 
@@ -125,14 +126,14 @@ def main() -> None:
                          agent_offset=rank * n)
     rt = GpuRolloutQLearning(algo, ExponentialSchedule(0.1, 1e-5, 0.995),
                              ExponentialSchedule(1.0, 0.01, 0.995), learn_mode=args.mode)
-    if world > 1:
+    if use_dist:
         from dist_classicrl_amd.distributed.delta_sync import attach_engine
 
         rt.sync_every = SYNC_EVERY
         rt.delta_sync = attach_engine(algo, SYNC_EVERY, n)
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             import torch
 
             dist.barrier()
@@ -146,15 +147,14 @@ def main() -> None:
     sync_all()
     elapsed = time.perf_counter() - t0
     stats = dict(rt.last_stats)
-    if world > 1:
+    if use_dist:
         import torch
 
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     env_steps = args.steps * n * n_gpus
@@ -182,7 +182,7 @@ def main() -> None:
                         f"fp32 Q-table, HashTabularEnv{' (masked)' if wl['masked'] else ''}, "
                         f"learn={args.mode}, benchmark-default schedules",
             "agents_per_gpu": n, "states": wl["states"], "actions": wl["actions"],
-            "sync_every": SYNC_EVERY if n_gpus > 1 else None,
+            "sync_every": SYNC_EVERY if use_dist else None,
             "parallelism": f"agents sharded x{n_gpus}, table replicas + RCCL delta all-gather" if n_gpus > 1 else "1 GPU",
         },
         "roofline": {
@@ -206,8 +206,10 @@ def main() -> None:
     if not args.no_cpu_baseline and n_gpus == 1:
         line["cpu_baseline"] = cpu_baseline(wl)
         line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    if use_dist:
+        line["delta_sync"] = {"syncs": rt.delta_sync.syncs, "bytes_received_per_gpu": rt.delta_sync.bytes_exchanged}
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

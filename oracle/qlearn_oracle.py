@@ -164,26 +164,37 @@ class OracleQLearning:
             return self.choose_actions_iter(states, action_masks=action_masks, **kw)
         return self.choose_actions_vec_iter(states, action_masks=action_masks, **kw)
 
+    # ------------------------------------------------------------------ table accessors (:100-233)
+    # kept as methods (not inlined) so that the per-transition call overhead matches the reference's
+    def get_q_value(self, state, action):
+        return self.q_table[state, action]
+
+    def get_state_q_values(self, state):
+        return self.q_table[state]
+
+    def add_q_value(self, state, action, value):
+        self.q_table[state, action] += value
+
     # ------------------------------------------------------------------ learning
     def single_learn(self, state, action, reward, next_state, terminated, lr, next_action_mask=None):
         # :728-768 -- target = r + gamma * max_valid Q[s'] (0 when terminated); in-place update.
-        if terminated:
-            nxt = 0
-        elif next_action_mask is None:
-            nxt = np.max(self.q_table[next_state])
+        if next_action_mask is None:
+            nxt = 0 if terminated else np.max(self.get_state_q_values(next_state))
         else:
-            nxt = np.max(self.q_table[next_state][np.where(next_action_mask)])
+            nxt = 0 if terminated else np.max(self.get_state_q_values(next_state)[np.where(next_action_mask)])
         target = reward + self.discount_factor * nxt
-        self.q_table[state, action] += lr * (target - self.q_table[state, action])
+        prediction = self.get_q_value(state, action)
+        self.add_q_value(state, action, lr * (target - prediction))
 
     def learn_iter(self, states, actions, rewards, next_states, terminated, lr, next_action_masks=None):
         # :770-817 -- strictly sequential over agents (agent i sees the writes of agents < i).
         if next_action_masks is None:
-            for tr in zip(states, actions, rewards, next_states, terminated, strict=True):
-                self.single_learn(*tr, lr)
+            for s, a, r, s2, te in zip(states, actions, rewards, next_states, terminated, strict=True):
+                self.single_learn(s, a, r, s2, te, lr)
         else:
-            for *tr, m in zip(states, actions, rewards, next_states, terminated, next_action_masks, strict=True):
-                self.single_learn(*tr, lr, m)
+            for s, a, r, s2, te, m in zip(states, actions, rewards, next_states, terminated,
+                                          next_action_masks, strict=True):
+                self.single_learn(s, a, r, s2, te, lr, m)
 
     def learn_vec(self, states, actions, rewards, next_states, terminated, lr, next_action_masks=None):
         # :819-891 + add_q_values :235-250 -- all reads precede all writes; duplicates accumulate.

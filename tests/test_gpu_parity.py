@@ -251,3 +251,39 @@ def test_full_size_properties(n, S, A, masked):
     val = envs.HashTabularEnv(n, S, A, seed=1, masked=masked)
     rt.evaluate_steps(val, 20 * n)
     assert np.array_equal(np.asarray(algo.q_table), q)
+
+
+# ------------------------------------------------------------------------------- full sizes, bit-exact
+@pytest.mark.parametrize(
+    ("name", "n", "S", "A", "masked", "steps"),
+    [
+        ("headline", 128, 1_000_000, 16, False, 3000),
+        ("c2", 128, 10_000, 8, False, 1500),
+        ("c3", 4096, 1_000_000, 16, False, 150),
+        ("c5", 1024, 1_000_000, 64, True, 100),
+        ("c4-one-shard", 8192, 10_000_000, 32, False, 40),
+    ],
+)
+def test_full_size_bit_exact_against_c_oracle(name, n, S, A, masked, steps):
+    """BASELINE.json's configurations at full size, benchmark-default schedules: every action of every
+    step, the whole Q-table, the episode returns and the final observations must equal the C oracle
+    (oracle/qlearn_oracle.c, itself pinned to the NumPy oracle and through it to the reference)."""
+    from oracle import c_oracle
+
+    Algo, Runtime, envs, sch = _product()
+    algo = Algo(S, A, 0.99, seed=0)
+    env = envs.HashTabularEnv(n, S, A, seed=1, masked=masked)
+    rt = Runtime(algo, sch.ExponentialSchedule(0.1, 1e-5, 0.995), sch.ExponentialSchedule(1.0, 0.01, 0.995))
+    rt.trace_actions = True
+    _avg, history, _, sd = rt.run_steps(steps, env, None)
+    ref = c_oracle.CHashRollout(n, S, A, masked=masked, dtype=np.float32)
+    eps, _ = c_oracle.exp_schedule(1.0, 0.01, 0.995, n, steps)
+    lr, _ = c_oracle.exp_schedule(0.1, 1e-5, 0.995, n, steps)
+    want = ref.run(eps, lr, trace=True)
+    assert np.array_equal(rt.trace_actions, want["actions"])
+    got_q = np.asarray(algo.q_table)
+    assert np.array_equal(got_q, ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    obs = sd["states"]["observation"] if masked else sd["states"]
+    assert np.array_equal(obs, ref.obs)
+    assert np.array_equal(sd["rewards"], ref.acc)

@@ -293,3 +293,40 @@ def test_train_contract():
     rewards, val_rewards, env2, sd = rt.train(env, steps=10, val_env=val, val_every_n_steps=5, val_episodes=2)
     assert len(rewards) == 8 and all(r == 5.0 for r in rewards)  # 2 chunks x 4 agents, re-reset per chunk
     assert val_rewards == [10.0, 10.0] and env2 is env and "rewards" in sd
+
+
+# ----------------------------------------------------------------------------- replica sync on device
+def test_delta_log_and_apply_reproduce_a_replica():
+    """Multi-GPU building blocks on one GPU: engine A learns with the delta log attached (buffer and
+    stream owned by torch, as under RCCL); applying A's records to engine B (zero table) must
+    reproduce A's table up to float32 summation order."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+
+    from dist_classicrl_amd import _lib
+    from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
+    from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
+    from dist_classicrl_amd.environments import HashTabularEnv
+    from dist_classicrl_amd.schedules import ConstantSchedule
+
+    lib = _lib.load()
+    n, S, A, steps = 96, 3000, 16, 50
+    for path in ("persistent", "stepwise"):
+        a = OptimalQLearningBase(S, A, 0.99, seed=0)
+        b = OptimalQLearningBase(S, A, 0.99, seed=0)
+        a.set_rollout_path(path)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.qe_set_stream(a.handle, stream))
+        _lib.check(lib.qe_set_stream(b.handle, stream))
+        log = torch.zeros((steps * n, 2), dtype=torch.int32, device="cuda")
+        _lib.check(lib.qe_delta_log_attach(a.handle, C.c_void_p(log.data_ptr()), steps * n))
+        rt = GpuRolloutQLearning(a, ConstantSchedule(0.1), ConstantSchedule(0.2))
+        rt.run_steps(steps, HashTabularEnv(n, S, A, seed=1), None)
+        assert lib.qe_delta_log_count(a.handle) == steps * n
+        _lib.check(lib.qe_delta_apply_dev(b.handle, C.c_void_p(log.data_ptr()), steps * n))
+        torch.cuda.synchronize()
+        qa, qb = np.asarray(a.q_table), np.asarray(b.q_table)
+        assert np.count_nonzero(qa) > 500
+        assert np.allclose(qa, qb, rtol=1e-5, atol=1e-6)
+        cells = log[:, 0].cpu().numpy()
+        assert cells.min() >= 0 and cells.max() < S * A
