@@ -164,6 +164,13 @@ def main() -> None:
     units_per_launch = stats["dominant_env_steps"] / launches
     achieved = bpe * units_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
     persistent = stats["launches"] < args.steps
+    traffic = None  # HBM bytes per launch from the PMC passes kept under profiles/ (same kernel, same workload)
+    try:
+        prof = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text()).get(args.workload)
+        if prof and persistent and "persistent" in prof["kernel"]:
+            traffic = prof["traffic_bytes_per_env_step"] * units_per_launch
+    except (OSError, ValueError, KeyError):
+        pass
     line = {
         "metric": "env-steps/sec at 128 agents, 1e6x16 Q-table; 1/2/4/8 GPU + HBM GB/s %peak",
         "value": env_steps / elapsed,
@@ -192,7 +199,7 @@ def main() -> None:
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic,
             "alg_bytes_per_env_step": bpe,
             "units_per_launch": units_per_launch,
             "avg_launch_us": avg_launch_s * 1e6,
