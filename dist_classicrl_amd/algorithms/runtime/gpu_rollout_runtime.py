@@ -100,6 +100,8 @@ class GpuRolloutQLearning(BaseRuntime):
             for f in total:
                 total[f] += getattr(st, f)
             done += k
+        if learn and self.delta_sync is not None:
+            self.delta_sync.flush()  # remote deltas still in flight are applied before returning
         self.last_stats = total
         if traces:
             self.trace_actions = np.concatenate(traces)

@@ -59,6 +59,27 @@ struct DevBuf {
     }
 };
 
+template <typename U>
+struct PinnedBuf {  // page-locked host staging: async copies without a host-side temporary
+    U* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max(n + n / 2, (size_t)1024);
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(U), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 int lanes_per_row(int ld) {  // smallest power of two L with 4*L >= ld
     int L = 1;
     while (4 * L < ld) L <<= 1;
@@ -101,6 +122,10 @@ struct qe_engine {
     long long dlog_cap = 0, dlog_count = 0;
     DevBuf<int32_t> trace;
     std::vector<hipEvent_t> sample_ev;  // event pairs around sampled dominant-kernel launches
+    PinnedBuf<unsigned long long> h_thr, h_key;
+    PinnedBuf<double> h_lr;
+    PinnedBuf<float> h_ret;
+    PinnedBuf<Ctrl> h_ctrl;
     size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
 };
 
@@ -164,18 +189,16 @@ unsigned long long eps_threshold(double eps) {
 }
 
 int upload_schedules(qe_engine* e, int64_t steps, const double* eps, const double* lr) {
-    std::vector<unsigned long long> thr((size_t)steps);
-    for (int64_t t = 0; t < steps; ++t) thr[(size_t)t] = eps ? eps_threshold(eps[t]) : 0ull;
+    HIP_TRY(e->h_thr.ensure((size_t)steps));
+    HIP_TRY(e->h_lr.ensure((size_t)steps));
+    for (int64_t t = 0; t < steps; ++t) e->h_thr.p[t] = eps ? eps_threshold(eps[t]) : 0ull;
+    if (lr) memcpy(e->h_lr.p, lr, steps * sizeof(double));
+    else memset(e->h_lr.p, 0, steps * sizeof(double));
     HIP_TRY(e->thr.ensure((size_t)steps));
     HIP_TRY(e->lr.ensure((size_t)steps));
-    HIP_TRY(hipMemcpyAsync(e->thr.p, thr.data(), steps * sizeof(unsigned long long),
-                           hipMemcpyHostToDevice, e->stream));
-    if (lr) {
-        HIP_TRY(hipMemcpyAsync(e->lr.p, lr, steps * sizeof(double), hipMemcpyHostToDevice, e->stream));
-    } else {
-        HIP_TRY(hipMemsetAsync(e->lr.p, 0, steps * sizeof(double), e->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(e->stream));  // `thr` is a host temporary
+    // staged in page-locked memory owned by the engine: no synchronisation needed here
+    HIP_TRY(hipMemcpyAsync(e->thr.p, e->h_thr.p, steps * sizeof(unsigned long long), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->lr.p, e->h_lr.p, steps * sizeof(double), hipMemcpyHostToDevice, e->stream));
     return QE_OK;
 }
 
@@ -220,9 +243,7 @@ int rollout_impl(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, 
     if (e->dlog && learn) {
         c.dlog = e->dlog; c.dlog_base = e->dlog_count; c.dlog_cap = e->dlog_cap;
     }
-    Ctrl init{};
-    HIP_TRY(hipMemcpyAsync(e->ctrl, &init, sizeof init, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
     int64_t launches = 0;
     int n_samples = 0;
     HIP_TRY(hipEventRecord(e->ev0, e->stream));
@@ -271,22 +292,24 @@ int rollout_impl(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, 
         ++launches;
     }
     HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(e->h_ctrl.ensure(1));
+    HIP_TRY(hipMemcpyAsync(e->h_ctrl.p, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    Ctrl fin{};
-    HIP_TRY(hipMemcpy(&fin, e->ctrl, sizeof fin, hipMemcpyDeviceToHost));
+    const Ctrl fin = *e->h_ctrl.p;
     // episode log -> host, sorted by (step, agent) = append order of base_runtime.py:218-221
     const long long got = std::min<long long>((long long)fin.ep_count, e->ep_cap);
-    std::vector<unsigned long long> keys((size_t)got);
-    std::vector<float> rets((size_t)got);
-    if (got) {
-        HIP_TRY(hipMemcpy(keys.data(), e->ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(rets.data(), e->ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost));
-    }
     e->ep_host.resize((size_t)got);
-    for (long long k = 0; k < got; ++k) e->ep_host[(size_t)k] = {keys[(size_t)k], rets[(size_t)k]};
+    if (got) {
+        HIP_TRY(e->h_key.ensure((size_t)got));
+        HIP_TRY(e->h_ret.ensure((size_t)got));
+        HIP_TRY(hipMemcpyAsync(e->h_key.p, e->ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->h_ret.p, e->ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (long long k = 0; k < got; ++k) e->ep_host[(size_t)k] = {e->h_key.p[k], e->h_ret.p[k]};
+    }
     std::sort(e->ep_host.begin(), e->ep_host.end(),
               [](const auto& x, const auto& y) { return x.first < y.first; });
     if (trace_host)
@@ -410,6 +433,7 @@ int qe_destroy(qe_engine* e) {
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     for (hipEvent_t x : e->sample_ev) (void)hipEventDestroy(x);
+    e->h_thr.release(); e->h_key.release(); e->h_lr.release(); e->h_ret.release(); e->h_ctrl.release();
     e->thr.release(); e->lr.release(); e->b_s.release(); e->b_a.release(); e->b_n.release();
     e->b_out.release(); e->b_list.release(); e->b_r.release(); e->b_acc.release(); e->b_term.release();
     e->b_pred.release(); e->b_aux.release(); e->b_mask.release(); e->b_bitmap.release();

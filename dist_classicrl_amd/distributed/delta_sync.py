@@ -12,9 +12,14 @@ the table.  Here every GPU owns ``N/G`` agents, their environments AND a full re
   the OTHER GPUs' deltas into its replica (``qe_delta_apply_dev``: fp32 atomicAdd scatter).
 
 Traffic per sync is proportional to the agent-steps taken, not to the table: 100 steps x 8192 agents
-x 8 B = 6.5 MB per GPU against 2.2 GB for a dense all-reduce of the 1e7 x 32 table.  Between syncs
-replicas drift (bounded staleness, the same family of semantics as the reference's asynchronous
-runtimes); with ``sync_every = 1`` every replica sees every update after each step.
+x 8 B = 6.5 MB per GPU against 2.2 GB for a dense all-reduce of the 1e7 x 32 table.
+
+Overlap (default): the all-gather of chunk k is started asynchronously and completes on the
+collective's own stream while chunk k+1 is being computed into the second log buffer; the remote
+deltas of chunk k are applied when chunk k+1 ends.  Remote updates therefore become visible
+``sync_every`` to ``2 * sync_every`` steps after they were made (bounded staleness -- the same
+family of semantics as the reference's asynchronous runtimes, which apply updates whenever a worker
+message happens to arrive).  ``overlap=False`` applies them at the sync point itself.
 
 torch is plumbing here (device buffers + the RCCL/gloo collective); ``apply_fn`` is the engine's
 scatter-add on GPU and an oracle function in the CPU (gloo) tests.
@@ -27,37 +32,83 @@ import torch.distributed as dist
 
 
 class DeltaSync:
-    def __init__(self, capacity: int, device, apply_fn, group=None) -> None:
+    def __init__(self, capacity: int, device, apply_fn, attach_fn=None, group=None, overlap: bool = True) -> None:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.capacity = int(capacity)
         self.apply_fn = apply_fn
-        self.log = torch.zeros((self.capacity, 2), dtype=torch.int32, device=device)
-        self.gathered = torch.zeros((self.world, self.capacity, 2), dtype=torch.int32, device=device)
+        self.attach_fn = attach_fn  # called with the log tensor the engine must write next
+        self.overlap = bool(overlap)
+        n_buf = 2 if self.overlap else 1
+        self.logs = [torch.zeros((self.capacity, 2), dtype=torch.int32, device=device) for _ in range(n_buf)]
+        self.gathered = [
+            torch.zeros((self.world, self.capacity, 2), dtype=torch.int32, device=device) for _ in range(n_buf)
+        ]
+        self.cur = 0
+        self._inflight = None  # (work handle or None, buffer index, record count)
         self.bytes_exchanged = 0
         self.syncs = 0
+        if self.attach_fn is not None:
+            self.attach_fn(self.log)
+
+    @property
+    def log(self) -> torch.Tensor:
+        """The buffer the engine is currently appending to."""
+        return self.logs[self.cur]
+
+    # ------------------------------------------------------------------ collective + apply
+    def _start(self, buf: int, count: int):
+        out, inp = self.gathered[buf], self.logs[buf]
+        try:
+            work = dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group, async_op=self.overlap)
+        except (RuntimeError, NotImplementedError):  # backends without the flat form
+            work = dist.all_gather([out[r] for r in range(self.world)], inp, group=self.group, async_op=self.overlap)
+        return work
+
+    def _finish(self, work, buf: int, count: int) -> None:
+        if work is not None:
+            work.wait()  # the current stream now waits for the collective; the host does not block
+        g = self.gathered[buf]
+        if count == self.capacity and self.world > 2:
+            # full segments are contiguous: everything before / after my own segment in two launches
+            if self.rank > 0:
+                self.apply_fn(g[: self.rank].reshape(-1, 2), count * self.rank)
+            if self.rank < self.world - 1:
+                self.apply_fn(g[self.rank + 1:].reshape(-1, 2), count * (self.world - 1 - self.rank))
+        else:
+            for r in range(self.world):
+                if r != self.rank:
+                    self.apply_fn(g[r], count)
+        self.bytes_exchanged += count * 8 * (self.world - 1)
 
     def exchange(self, count: int) -> None:
-        """All-gather the first ``count`` log records of every rank, apply the remote ones."""
+        """Publish the first ``count`` records of the current log; apply what has arrived."""
         if count > self.capacity:
             msg = f"delta log overflow: {count} records, capacity {self.capacity}"
             raise RuntimeError(msg)
         if count == 0:
             return
-        try:
-            dist.all_gather_into_tensor(self.gathered.view(-1), self.log.view(-1), group=self.group)
-        except (RuntimeError, NotImplementedError):  # backends without the flat form
-            parts = [self.gathered[r] for r in range(self.world)]
-            dist.all_gather(parts, self.log, group=self.group)
-        for r in range(self.world):
-            if r != self.rank:
-                self.apply_fn(self.gathered[r], count)
-        self.bytes_exchanged += count * 8 * (self.world - 1)
         self.syncs += 1
+        if not self.overlap:
+            self._finish(self._start(0, count), 0, count)
+            return
+        previous = self._inflight
+        self._inflight = (self._start(self.cur, count), self.cur, count)
+        self.cur ^= 1
+        if self.attach_fn is not None:
+            self.attach_fn(self.log)  # the engine fills the other buffer while this one travels
+        if previous is not None:
+            self._finish(*previous)
+
+    def flush(self) -> None:
+        """Complete the exchange that is still in flight (end of a training call)."""
+        if self._inflight is not None:
+            self._finish(*self._inflight)
+            self._inflight = None
 
 
-def attach_engine(algorithm, sync_every: int, num_agents: int, group=None) -> DeltaSync:
+def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overlap: bool = True) -> DeltaSync:
     """Wire a :class:`DeltaSync` to a HIP engine living on the current CUDA device."""
     import ctypes as C
 
@@ -67,10 +118,12 @@ def attach_engine(algorithm, sync_every: int, num_agents: int, group=None) -> De
     dev = torch.device("cuda", torch.cuda.current_device())
     # run the engine on torch's current stream so collectives and kernels are stream-ordered
     _lib.check(lib.qe_set_stream(algorithm.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    capacity = sync_every * num_agents
 
     def apply_fn(entries, count):
         _lib.check(lib.qe_delta_apply_dev(algorithm.handle, C.c_void_p(entries.data_ptr()), int(count)))
 
-    sync = DeltaSync(sync_every * num_agents, dev, apply_fn, group)
-    _lib.check(lib.qe_delta_log_attach(algorithm.handle, C.c_void_p(sync.log.data_ptr()), sync.capacity))
-    return sync
+    def attach_fn(log):
+        _lib.check(lib.qe_delta_log_attach(algorithm.handle, C.c_void_p(log.data_ptr()), capacity))
+
+    return DeltaSync(capacity, dev, apply_fn, attach_fn, group, overlap)

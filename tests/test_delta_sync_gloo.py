@@ -40,7 +40,7 @@ def _apply(q, cells, deltas):
     np.add.at(q.reshape(-1), cells, deltas)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dist_classicrl_amd.distributed.delta_sync import DeltaSync
@@ -53,37 +53,49 @@ def _worker(rank, world, port, out_dir):
         _apply(run.q, e[:, 0], e[:, 1].view(np.float32))
 
     cap = S * A
-    sync = DeltaSync(cap, "cpu", apply_fn)
+    sync = DeltaSync(cap, "cpu", apply_fn, overlap=overlap)
     for k in range(CHUNKS):
         cells, deltas = _run_chunk(run, k)
         # every rank must exchange the same record count: pad with (cell 0, +0.0) no-ops
         cnt = torch.tensor([cells.size])
         dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
         count = int(cnt.item())
-        sync.log.zero_()
-        sync.log[:cells.size, 0] = torch.from_numpy(cells)
-        sync.log[:cells.size, 1] = torch.from_numpy(deltas.view(np.int32))
+        log = sync.log  # the buffer the "engine" writes this chunk's records into
+        log.zero_()
+        log[:cells.size, 0] = torch.from_numpy(cells)
+        log[:cells.size, 1] = torch.from_numpy(deltas.view(np.int32))
         sync.exchange(count)
+    sync.flush()
     np.save(os.path.join(out_dir, f"q{rank}.npy"), run.q)
     np.save(os.path.join(out_dir, f"obs{rank}.npy"), run.obs)
     assert sync.syncs == CHUNKS
     dist.destroy_process_group()
 
 
-def test_two_rank_replica_sync_matches_single_process_simulation(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_replica_sync_matches_single_process_simulation(tmp_path, overlap):
     from oracle import c_oracle
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
     q0, q1 = np.load(tmp_path / "q0.npy"), np.load(tmp_path / "q1.npy")
 
+    # single-process simulation of the same protocol: without overlap the other rank's records are
+    # applied at the sync point, with overlap one chunk later (and at the final flush)
     runs = [c_oracle.CHashRollout(N_PER_RANK, S, A, agent_offset=r * N_PER_RANK, dtype=np.float32) for r in (0, 1)]
+    late = None
     for k in range(CHUNKS):
         recs = [_run_chunk(run, k) for run in runs]
-        _apply(runs[0].q, *recs[1])
-        _apply(runs[1].q, *recs[0])
+        ready = late if overlap else recs
+        if ready is not None:
+            _apply(runs[0].q, *ready[1])
+            _apply(runs[1].q, *ready[0])
+        late = recs
+    if overlap:
+        _apply(runs[0].q, *late[1])
+        _apply(runs[1].q, *late[0])
     assert np.array_equal(q0, runs[0].q) and np.array_equal(q1, runs[1].q)
     assert np.count_nonzero(q0) > 100
     assert np.allclose(q0, q1, rtol=1e-5, atol=1e-6)  # same sums, different fp32 summation order
