@@ -90,6 +90,8 @@ PROTOTYPES = {
     "qe_env_aux": (C.c_int, [_P, _U32P]),
     "qe_env_step": (C.c_int, [_P, _I32P, _I32P, _F32P, _U8P, _U8P]),
     "qe_rollout": (C.c_int, [_P, _P, C.c_int64, _F64P, _F64P, C.c_int32, _I32P, C.POINTER(RolloutStats)]),
+    "qe_rollout_begin": (C.c_int, [_P, _P, C.c_int64, _F64P, _F64P, C.c_int32, C.c_int32]),
+    "qe_rollout_end": (C.c_int, [_P, C.c_int32, C.POINTER(RolloutStats)]),
     "qe_evaluate": (C.c_int, [_P, _P, C.c_int64, C.POINTER(RolloutStats)]),
     "qe_episode_log": (C.c_int64, [_P, C.c_int64, _I32P, _I32P, _F32P]),
     "qe_delta_log_attach": (C.c_int, [_P, _P, C.c_int64]),

@@ -60,6 +60,19 @@ class GpuRolloutQLearning(BaseRuntime):
         return env
 
     # ------------------------------------------------------------------ fused rollout
+    _PIPELINE_CHUNK = 2000  # vector steps per launch when nothing else (log capacity, sync cadence) binds
+
+    def _collect(self, lib, algo, st, done, total, history, ep_steps):
+        cnt = int(lib.qe_episode_log(algo.handle, 0, None, None, None))
+        if cnt:
+            step_idx = np.empty(cnt, dtype=np.int32)
+            ret = np.empty(cnt, dtype=np.float32)
+            lib.qe_episode_log(algo.handle, cnt, _lib.ptr(step_idx, C.c_int32), None, _lib.ptr(ret, C.c_float))
+            history.append(ret)
+            ep_steps.append(step_idx + done)
+        for f in total:
+            total[f] += getattr(st, f)
+
     def _rollout(self, env, steps, learn):
         lib = _lib.load()
         algo = self.algorithm
@@ -69,39 +82,63 @@ class GpuRolloutQLearning(BaseRuntime):
                  "dominant_ms": 0.0, "dominant_launches": 0, "dominant_env_steps": 0}
         history, ep_steps, traces = [], [], []
         chunk_max = max(1, _EP_LOG_CAPACITY // n)
-        if learn and self.delta_sync is not None:
+        sync = self.delta_sync if learn else None
+        if sync is not None:
             chunk_max = min(chunk_max, self.sync_every)
-        done = 0
-        while done < steps:
-            k = min(chunk_max, steps - done)
-            st = _lib.RolloutStats()
-            if learn:
-                eps = _schedule_values(self.exploration_rate_schedule, n, k)
-                lr = _schedule_values(self.lr_schedule, n, k)
-                trace = np.empty((k, n), dtype=np.int32) if self.trace_actions else None
-                _lib.check(lib.qe_rollout(algo.handle, env.handle, k, _lib.ptr(eps, C.c_double),
-                                          _lib.ptr(lr, C.c_double), mode, _lib.ptr(trace, C.c_int32),
-                                          C.byref(st)))
-                if trace is not None:
-                    traces.append(trace)
-                if self.delta_sync is not None:
-                    # replicas exchange the (cell, delta) records of this chunk (RCCL all-gather)
-                    self.delta_sync.exchange(int(lib.qe_delta_log_count(algo.handle)))
+        if learn and not self.trace_actions:
+            # Pipelined: chunk k+1 is enqueued before the results of chunk k are read back, so the GPU
+            # never waits for the host (schedule arithmetic, episode-log handling, replica exchange).
+            chunk_max = min(chunk_max, self._PIPELINE_CHUNK)
+            sizes = [min(chunk_max, steps - d) for d in range(0, steps, chunk_max)]
+            starts = np.cumsum([0] + sizes[:-1])
+
+            def begin(k):
+                eps = _schedule_values(self.exploration_rate_schedule, n, sizes[k])
+                lr = _schedule_values(self.lr_schedule, n, sizes[k])
+                _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, sizes[k], _lib.ptr(eps, C.c_double),
+                                                _lib.ptr(lr, C.c_double), mode, k & 1))
+
+            def end(k):
+                st = _lib.RolloutStats()
+                _lib.check(lib.qe_rollout_end(algo.handle, k & 1, C.byref(st)))
+                self._collect(lib, algo, st, int(starts[k]), total, history, ep_steps)
+
+            def exchange(k):
+                if sync is not None:  # all-gather of chunk k's (cell, delta) records, stream-ordered
+                    sync.exchange(sizes[k] * n)
                     _lib.check(lib.qe_delta_log_reset(algo.handle))
-            else:
-                _lib.check(lib.qe_evaluate(algo.handle, env.handle, k, C.byref(st)))
-            cnt = int(lib.qe_episode_log(algo.handle, 0, None, None, None))
-            if cnt:
-                step_idx = np.empty(cnt, dtype=np.int32)
-                ret = np.empty(cnt, dtype=np.float32)
-                lib.qe_episode_log(algo.handle, cnt, _lib.ptr(step_idx, C.c_int32), None, _lib.ptr(ret, C.c_float))
-                history.append(ret)
-                ep_steps.append(step_idx + done)
-            for f in total:
-                total[f] += getattr(st, f)
-            done += k
-        if learn and self.delta_sync is not None:
-            self.delta_sync.flush()  # remote deltas still in flight are applied before returning
+
+            begin(0)
+            for k in range(1, len(sizes)):
+                exchange(k - 1)
+                begin(k)
+                end(k - 1)
+            exchange(len(sizes) - 1)
+            end(len(sizes) - 1)
+            if sync is not None:
+                sync.flush()  # remote deltas still in flight are applied before returning
+        else:
+            done = 0
+            while done < steps:
+                k = min(chunk_max, steps - done)
+                st = _lib.RolloutStats()
+                if learn:
+                    eps = _schedule_values(self.exploration_rate_schedule, n, k)
+                    lr = _schedule_values(self.lr_schedule, n, k)
+                    trace = np.empty((k, n), dtype=np.int32)
+                    _lib.check(lib.qe_rollout(algo.handle, env.handle, k, _lib.ptr(eps, C.c_double),
+                                              _lib.ptr(lr, C.c_double), mode, _lib.ptr(trace, C.c_int32),
+                                              C.byref(st)))
+                    traces.append(trace)
+                    if sync is not None:
+                        sync.exchange(k * n)
+                        _lib.check(lib.qe_delta_log_reset(algo.handle))
+                else:
+                    _lib.check(lib.qe_evaluate(algo.handle, env.handle, k, C.byref(st)))
+                self._collect(lib, algo, st, done, total, history, ep_steps)
+                done += k
+            if sync is not None:
+                sync.flush()
         self.last_stats = total
         if traces:
             self.trace_actions = np.concatenate(traces)

@@ -88,6 +88,37 @@ int lanes_per_row(int ld) {  // smallest power of two L with 4*L >= ld
 
 }  // namespace
 
+// Everything one in-flight rollout owns, so that the next rollout can be enqueued before the results
+// of the previous one are read back.
+struct RolloutSlot {
+    Ctrl* ctrl = nullptr;
+    DevBuf<unsigned long long> thr, ep_key;
+    DevBuf<double> lr;
+    DevBuf<float> ep_ret;
+    PinnedBuf<unsigned long long> h_thr, h_key;
+    PinnedBuf<double> h_lr;
+    PinnedBuf<float> h_ret;
+    PinnedBuf<Ctrl> h_ctrl;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, sched_ready = nullptr;
+    std::vector<hipEvent_t> sample_ev;  // event pairs around sampled dominant-kernel launches
+    bool busy = false, persistent = false;
+    int n_samples = 0;
+    int64_t steps = 0, N = 0, launches = 0;
+    int32_t* trace_host = nullptr;
+    void release() {
+        if (ctrl) (void)hipFree(ctrl);
+        ctrl = nullptr;
+        thr.release(); ep_key.release(); lr.release(); ep_ret.release();
+        h_thr.release(); h_key.release(); h_lr.release(); h_ret.release(); h_ctrl.release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (sched_ready) (void)hipEventDestroy(sched_ready);
+        for (hipEvent_t x : sample_ev) (void)hipEventDestroy(x);
+        sample_ev.clear();
+        ev0 = ev1 = sched_ready = nullptr;
+    }
+};
+
 struct qe_engine {
     int device = 0;
     int dtype = QE_F32;
@@ -121,11 +152,8 @@ struct qe_engine {
     DeltaEntry* dlog = nullptr;
     long long dlog_cap = 0, dlog_count = 0;
     DevBuf<int32_t> trace;
-    std::vector<hipEvent_t> sample_ev;  // event pairs around sampled dominant-kernel launches
-    PinnedBuf<unsigned long long> h_thr, h_key;
-    PinnedBuf<double> h_lr;
-    PinnedBuf<float> h_ret;
-    PinnedBuf<Ctrl> h_ctrl;
+    hipStream_t copy_stream = nullptr;  // result read-back beside the compute stream
+    RolloutSlot slots[2];               // two rollouts may be in flight (begin k+1 before end k)
     size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
 };
 
@@ -188,17 +216,29 @@ unsigned long long eps_threshold(double eps) {
     return v >= 4294967296.0 ? (1ull << 32) : (unsigned long long)v;
 }
 
-int upload_schedules(qe_engine* e, int64_t steps, const double* eps, const double* lr) {
-    HIP_TRY(e->h_thr.ensure((size_t)steps));
-    HIP_TRY(e->h_lr.ensure((size_t)steps));
-    for (int64_t t = 0; t < steps; ++t) e->h_thr.p[t] = eps ? eps_threshold(eps[t]) : 0ull;
-    if (lr) memcpy(e->h_lr.p, lr, steps * sizeof(double));
-    else memset(e->h_lr.p, 0, steps * sizeof(double));
-    HIP_TRY(e->thr.ensure((size_t)steps));
-    HIP_TRY(e->lr.ensure((size_t)steps));
-    // staged in page-locked memory owned by the engine: no synchronisation needed here
-    HIP_TRY(hipMemcpyAsync(e->thr.p, e->h_thr.p, steps * sizeof(unsigned long long), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->lr.p, e->h_lr.p, steps * sizeof(double), hipMemcpyHostToDevice, e->stream));
+int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps, const double* lr) {
+    if (!sl.ctrl) {
+        HIP_TRY(hipMalloc((void**)&sl.ctrl, sizeof(Ctrl)));
+        HIP_TRY(hipEventCreate(&sl.ev0));
+        HIP_TRY(hipEventCreate(&sl.ev1));
+        HIP_TRY(hipEventCreateWithFlags(&sl.sched_ready, hipEventDisableTiming));
+        HIP_TRY(sl.ep_key.ensure((size_t)e->ep_cap));
+        HIP_TRY(sl.ep_ret.ensure((size_t)e->ep_cap));
+        HIP_TRY(sl.h_ctrl.ensure(1));
+    }
+    HIP_TRY(sl.h_thr.ensure((size_t)steps));
+    HIP_TRY(sl.h_lr.ensure((size_t)steps));
+    for (int64_t t = 0; t < steps; ++t) sl.h_thr.p[t] = eps ? eps_threshold(eps[t]) : 0ull;
+    if (lr) memcpy(sl.h_lr.p, lr, steps * sizeof(double));
+    else memset(sl.h_lr.p, 0, steps * sizeof(double));
+    HIP_TRY(sl.thr.ensure((size_t)steps));
+    HIP_TRY(sl.lr.ensure((size_t)steps));
+    // staged in page-locked memory owned by the slot and uploaded on the copy stream, so the two
+    // small copies overlap the rollout that is still running on the compute stream
+    HIP_TRY(hipMemcpyAsync(sl.thr.p, sl.h_thr.p, steps * sizeof(unsigned long long), hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipMemcpyAsync(sl.lr.p, sl.h_lr.p, steps * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipEventRecord(sl.sched_ready, e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(e->stream, sl.sched_ready, 0));
     return QE_OK;
 }
 
@@ -214,27 +254,27 @@ void pack_masks(const uint8_t* masks, int64_t n, int A, std::vector<uint32_t>& o
 constexpr int MAX_SAMPLES = 256;
 
 template <typename T, class Env>
-int launch_step(qe_engine* e, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow, int64_t* launches,
-                int sample = -1) {
-    if (sample >= 0) (void)hipEventRecord(e->sample_ev[2 * sample], e->stream);
+void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow,
+                 int sample = -1) {
+    if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample], e->stream);
     hipLaunchKernelGGL((k_step_fast<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK),
                        0, e->stream, c, ev, flags);
-    if (sample >= 0) (void)hipEventRecord(e->sample_ev[2 * sample + 1], e->stream);
-    ++*launches;
+    if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
+    ++sl.launches;
     if (slow) {
         hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
-        ++*launches;
+        ++sl.launches;
     }
-    return QE_OK;
 }
 
-
-
+// Enqueue one rollout (no host synchronisation): schedules, control block, kernels, events.
 template <typename T, class Env>
-int rollout_impl(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, int32_t* trace_host,
-                 qe_rollout_stats* st) {
+int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps, int mode, int learn,
+                       int32_t* trace_host) {
     Ctx<T> c = env_ctx<T>(e, env);
     c.mode = mode;
+    c.ctrl = sl.ctrl; c.thr = sl.thr.p; c.lr = sl.lr.p;
+    c.ep_key = sl.ep_key.p; c.ep_ret = sl.ep_ret.p; c.ep_cap = e->ep_cap;
     const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
     if (trace_host) {
         HIP_TRY(e->trace.ensure((size_t)(steps * env->N)));
@@ -243,15 +283,15 @@ int rollout_impl(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, 
     if (e->dlog && learn) {
         c.dlog = e->dlog; c.dlog_base = e->dlog_count; c.dlog_cap = e->dlog_cap;
     }
-    HIP_TRY(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
-    int64_t launches = 0;
-    int n_samples = 0;
-    HIP_TRY(hipEventRecord(e->ev0, e->stream));
     const int64_t lanes = env->N * e->L;
     const bool persistent = learn && lanes <= PERSIST_MAX_LANES && env->N <= PERSIST_MAX_AGENTS && e->opt_path != 1;
     if (learn && e->opt_path == 2 && !persistent)
         return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and num_agents * lanes_per_row <= 1024 (have %lld lanes)",
                     (long long)lanes);
+    sl.launches = 0; sl.n_samples = 0; sl.steps = steps; sl.N = env->N; sl.persistent = persistent;
+    sl.trace_host = trace_host;
+    if (!persistent) HIP_TRY(hipMemsetAsync(sl.ctrl, 0, sizeof(Ctrl), e->stream));  // persistent kernel: in-kernel
+    HIP_TRY(hipEventRecord(sl.ev0, e->stream));
     if (persistent) {
         const unsigned block = (unsigned)((lanes + 63) / 64 * 64);
         auto go = [&](auto lc) {
@@ -270,87 +310,91 @@ int rollout_impl(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, 
         } else {
             go(std::integral_constant<int, 1>{});  // GridLake (A = 4) and the bandit (A = 2): one lane per row
         }
-        ++launches;
+        ++sl.launches;
     } else if (learn) {
         const int base = FLAG_ACCOUNT;
-        launch_step<T, Env>(e, c, ev, base | FLAG_SELECT, false, &launches);  // select(0), env.step(0)
-        while ((int)e->sample_ev.size() < 2 * MAX_SAMPLES) {
+        launch_step<T, Env>(e, sl, c, ev, base | FLAG_SELECT, false);  // select(0), env.step(0)
+        while ((int)sl.sample_ev.size() < 2 * MAX_SAMPLES) {
             hipEvent_t evn;
             HIP_TRY(hipEventCreate(&evn));
-            e->sample_ev.push_back(evn);
+            sl.sample_ev.push_back(evn);
         }
         const int64_t stride = std::max<int64_t>(1, (steps - 1) / MAX_SAMPLES);
         for (int64_t t = 0; t + 1 < steps; ++t) {
-            const int sample = (t % stride == 0 && n_samples < MAX_SAMPLES) ? n_samples++ : -1;
-            launch_step<T, Env>(e, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, &launches, sample);
+            const int sample = (t % stride == 0 && sl.n_samples < MAX_SAMPLES) ? sl.n_samples++ : -1;
+            launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, sample);
         }
-        launch_step<T, Env>(e, c, ev, base | FLAG_LEARN, true, &launches);  // learn(steps-1)
+        launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN, true);  // learn(steps-1)
     } else {
         // greedy evaluation: no table writes, hence no contention and no ordered path
         hipLaunchKernelGGL((k_eval<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK), 0,
                            e->stream, c, ev, (long long)steps);
-        ++launches;
+        ++sl.launches;
     }
-    HIP_TRY(hipEventRecord(e->ev1, e->stream));
-    HIP_TRY(e->h_ctrl.ensure(1));
-    HIP_TRY(hipMemcpyAsync(e->h_ctrl.p, e->ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipEventRecord(sl.ev1, e->stream));
+    HIP_TRY(hipGetLastError());
+    if (c.dlog) e->dlog_count = std::min<long long>(e->dlog_count + steps * env->N, e->dlog_cap);
+    e->step_ctr += (uint64_t)steps;
+    sl.busy = true;
+    return QE_OK;
+}
+
+// Wait for one enqueued rollout and read its results back on the copy stream (the compute stream
+// may already be running the next rollout).
+int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
+    if (!sl.busy) return fail(QE_ERR_INVALID, "no rollout in flight in this slot");
+    sl.busy = false;
+    HIP_TRY(hipStreamWaitEvent(e->copy_stream, sl.ev1, 0));
+    HIP_TRY(hipMemcpyAsync(sl.h_ctrl.p, sl.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->copy_stream));
+    HIP_TRY(hipStreamSynchronize(e->copy_stream));
     HIP_TRY(hipGetLastError());
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    const Ctrl fin = *e->h_ctrl.p;
+    HIP_TRY(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
+    const Ctrl fin = *sl.h_ctrl.p;
     // episode log -> host, sorted by (step, agent) = append order of base_runtime.py:218-221
     const long long got = std::min<long long>((long long)fin.ep_count, e->ep_cap);
     e->ep_host.resize((size_t)got);
     if (got) {
-        HIP_TRY(e->h_key.ensure((size_t)got));
-        HIP_TRY(e->h_ret.ensure((size_t)got));
-        HIP_TRY(hipMemcpyAsync(e->h_key.p, e->ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->h_ret.p, e->ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        for (long long k = 0; k < got; ++k) e->ep_host[(size_t)k] = {e->h_key.p[k], e->h_ret.p[k]};
+        HIP_TRY(sl.h_key.ensure((size_t)got));
+        HIP_TRY(sl.h_ret.ensure((size_t)got));
+        HIP_TRY(hipMemcpyAsync(sl.h_key.p, sl.ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipMemcpyAsync(sl.h_ret.p, sl.ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+        for (long long k = 0; k < got; ++k) e->ep_host[(size_t)k] = {sl.h_key.p[k], sl.h_ret.p[k]};
     }
     std::sort(e->ep_host.begin(), e->ep_host.end(),
               [](const auto& x, const auto& y) { return x.first < y.first; });
-    if (trace_host)
-        HIP_TRY(hipMemcpy(trace_host, e->trace.p, steps * env->N * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (c.dlog) e->dlog_count = std::min<long long>(e->dlog_count + steps * env->N, e->dlog_cap);
-    e->step_ctr += (uint64_t)steps;
+    if (sl.trace_host) {
+        HIP_TRY(hipMemcpyAsync(sl.trace_host, e->trace.p, sl.steps * sl.N * sizeof(int32_t), hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    }
     if (st) {
-        st->kernel_ms = ms; st->launches = launches; st->episodes = (int64_t)fin.ep_count;
+        memset(st, 0, sizeof *st);
+        st->kernel_ms = ms; st->launches = sl.launches; st->episodes = (int64_t)fin.ep_count;
         st->involved = (int64_t)fin.involved_total;
         st->episodes_dropped = (int64_t)fin.ep_count - got;
-        for (int k = 0; k < n_samples; ++k) {
+        for (int k = 0; k < sl.n_samples; ++k) {
             float one = 0;
-            if (hipEventElapsedTime(&one, e->sample_ev[2 * k], e->sample_ev[2 * k + 1]) == hipSuccess)
+            if (hipEventElapsedTime(&one, sl.sample_ev[2 * k], sl.sample_ev[2 * k + 1]) == hipSuccess)
                 st->dominant_ms += one;
         }
-        st->dominant_launches = n_samples;
-        st->dominant_env_steps = (int64_t)n_samples * env->N;
-        if (persistent) {  // the one launch IS the timed region
-            st->dominant_ms = ms; st->dominant_launches = 1; st->dominant_env_steps = steps * env->N;
+        st->dominant_launches = sl.n_samples;
+        st->dominant_env_steps = (int64_t)sl.n_samples * sl.N;
+        if (sl.persistent) {  // the one launch IS the timed region
+            st->dominant_ms = ms; st->dominant_launches = 1; st->dominant_env_steps = sl.steps * sl.N;
         }
     }
-#ifdef QE_STAMPS
-    if (persistent) {
-        double seg[8];
-        (void)hipMemcpy(seg, env->vinc.p, sizeof seg, hipMemcpyDeviceToHost);
-        const char* names[8] = {"inserts", "barrier", "row issue+classify", "philox", "update+account",
-                                "select+env", "extended+flush", "loop top"};
-        for (int k = 0; k < 8; ++k) fprintf(stderr, "  [stamps] %-20s %8.1f ns/step\n", names[k], seg[k] * 10.0 / steps);
-    }
-#endif
     if (fin.error) return fail(QE_ERR_NO_DEVICE, "ordered path gave up (internal error %u)", fin.error);
     return QE_OK;
 }
 
 template <typename T>
-int rollout_dispatch(qe_engine* e, qe_env* env, int64_t steps, int mode, int learn, int32_t* trace,
-                     qe_rollout_stats* st) {
+int rollout_begin_dispatch(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps, int mode, int learn,
+                           int32_t* trace) {
     switch (env->p.kind) {
-        case QE_ENV_HASH: return rollout_impl<T, HashEnv>(e, env, steps, mode, learn, trace, st);
-        case QE_ENV_GRID: return rollout_impl<T, GridEnv>(e, env, steps, mode, learn, trace, st);
-        case QE_ENV_BANDIT: return rollout_impl<T, BanditEnv>(e, env, steps, mode, learn, trace, st);
+        case QE_ENV_HASH: return rollout_begin_impl<T, HashEnv>(e, env, sl, steps, mode, learn, trace);
+        case QE_ENV_GRID: return rollout_begin_impl<T, GridEnv>(e, env, sl, steps, mode, learn, trace);
+        case QE_ENV_BANDIT: return rollout_begin_impl<T, BanditEnv>(e, env, sl, steps, mode, learn, trace);
     }
     return fail(QE_ERR_INVALID, "unknown env kind %d", env->p.kind);
 }
@@ -402,13 +446,12 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     e->gamma = gamma; e->seed = seed;
     const size_t bytes = (size_t)S * e->ld * e->esize();
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipMalloc(&e->q, bytes);
     if (err == hipSuccess) err = hipMalloc((void**)&e->stamps, (size_t)S * 2 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc((void**)&e->ctrl, sizeof(Ctrl));
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
-    if (err == hipSuccess) err = e->ep_key.ensure((size_t)e->ep_cap);
-    if (err == hipSuccess) err = e->ep_ret.ensure((size_t)e->ep_cap);
     if (err == hipSuccess) err = hipMemsetAsync(e->q, 0, bytes, e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(e->stamps, 0, (size_t)S * 2 * sizeof(unsigned long long), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream);
@@ -432,8 +475,8 @@ int qe_destroy(qe_engine* e) {
     if (e->ctrl) (void)hipFree(e->ctrl);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
-    for (hipEvent_t x : e->sample_ev) (void)hipEventDestroy(x);
-    e->h_thr.release(); e->h_key.release(); e->h_lr.release(); e->h_ret.release(); e->h_ctrl.release();
+    e->slots[0].release(); e->slots[1].release();
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     e->thr.release(); e->lr.release(); e->b_s.release(); e->b_a.release(); e->b_n.release();
     e->b_out.release(); e->b_list.release(); e->b_r.release(); e->b_acc.release(); e->b_term.release();
     e->b_pred.release(); e->b_aux.release(); e->b_mask.release(); e->b_bitmap.release();
@@ -770,28 +813,47 @@ int qe_env_step(qe_env* env, const int32_t* actions, int32_t* obs, float* reward
 }
 
 // ---- fused rollout / evaluation ------------------------------------------------------------------
-static int run(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int mode,
-               int learn, int32_t* trace, qe_rollout_stats* st) {
+static int begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int mode,
+                 int learn, int32_t* trace, int slot) {
     if (!e || !env || env->e != e) return fail(QE_ERR_INVALID, "engine/env mismatch");
-    if (steps < 0) return fail(QE_ERR_INVALID, "steps must be >= 0");
-    if (st) memset(st, 0, sizeof *st);
-    e->ep_host.clear();
-    if (steps == 0) return QE_OK;
+    if (slot < 0 || slot > 1) return fail(QE_ERR_INVALID, "slot must be 0 or 1");
+    if (steps <= 0) return fail(QE_ERR_INVALID, "steps must be > 0");
     if (learn && (!eps || !lr)) return fail(QE_ERR_INVALID, "eps and lr schedules are required");
     if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
+    RolloutSlot& sl = e->slots[slot];
+    if (sl.busy) return fail(QE_ERR_INVALID, "slot %d still has a rollout in flight (call qe_rollout_end)", slot);
     HIP_TRY(hipSetDevice(e->device));
-    if (int rc = upload_schedules(e, steps, learn ? eps : nullptr, learn ? lr : nullptr)) return rc;
-    return e->dtype == QE_F32 ? rollout_dispatch<float>(e, env, steps, mode, learn, trace, st)
-                              : rollout_dispatch<double>(e, env, steps, mode, learn, trace, st);
+    if (int rc = slot_prepare(e, sl, steps, learn ? eps : nullptr, learn ? lr : nullptr)) return rc;
+    return e->dtype == QE_F32 ? rollout_begin_dispatch<float>(e, env, sl, steps, mode, learn, trace)
+                              : rollout_begin_dispatch<double>(e, env, sl, steps, mode, learn, trace);
+}
+
+int qe_rollout_begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
+                     int32_t mode, int32_t slot) {
+    return begin(e, env, steps, eps, lr, mode, 1, nullptr, slot);
+}
+
+int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats) {
+    if (!e || slot < 0 || slot > 1) return fail(QE_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    return rollout_end(e, e->slots[slot], stats);
 }
 
 int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int32_t mode,
                int32_t* trace_actions, qe_rollout_stats* stats) {
-    return run(e, env, steps, eps, lr, mode, 1, trace_actions, stats);
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (e) e->ep_host.clear();
+    if (steps == 0) return QE_OK;
+    if (int rc = begin(e, env, steps, eps, lr, mode, 1, trace_actions, 0)) return rc;
+    return rollout_end(e, e->slots[0], stats);
 }
 
 int qe_evaluate(qe_engine* e, qe_env* env, int64_t steps, qe_rollout_stats* stats) {
-    return run(e, env, steps, nullptr, nullptr, QE_LEARN_ITER, 0, nullptr, stats);
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (e) e->ep_host.clear();
+    if (steps == 0) return QE_OK;
+    if (int rc = begin(e, env, steps, nullptr, nullptr, QE_LEARN_ITER, 0, nullptr, 0)) return rc;
+    return rollout_end(e, e->slots[0], stats);
 }
 
 int64_t qe_episode_log(qe_engine* e, int64_t cap, int32_t* step, int32_t* agent, float* ret) {

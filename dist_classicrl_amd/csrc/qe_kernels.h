@@ -605,6 +605,8 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
     if (tid == 0) {
         lds.ep_n = 0u; lds.n_def = 0u; lds.n_rem = 0u; lds.complex_ = 0u;
         lds.busy[0] = lds.busy[1] = lds.busy[2] = 0u;
+        c.ctrl->error = 0u;  // this launch owns the control block: no host-side memset in front of it
+        c.ctrl->inv_count = 0u;
     }
     {   // select(0), env.step(0)
         const Row4<T> row = load_row4(c.q, p.n, c.ld, sub);
@@ -810,8 +812,9 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
 #endif
     if (lead) { c.n[i] = p.n; c.aux[i] = p.aux; c.acc[i] = acc; }
     if (tid == 0) {
-        c.ctrl->involved_total += deferred_total;
-        c.ctrl->ep_count += ep_base;
+        c.ctrl->involved_total = deferred_total;
+        c.ctrl->ep_count = ep_base;
+        c.ctrl->t_local = steps;
     }
 }
 

@@ -32,7 +32,9 @@ import torch.distributed as dist
 
 
 class DeltaSync:
-    def __init__(self, capacity: int, device, apply_fn, attach_fn=None, group=None, overlap: bool = True) -> None:
+    def __init__(self, capacity: int, device, apply_fn, attach_fn=None, group=None, overlap: bool = True,
+                 stream=None) -> None:
+        self.stream = stream  # torch.cuda.Stream the engine runs on (None on CPU / current stream)
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -82,8 +84,24 @@ class DeltaSync:
                     self.apply_fn(g[r], count)
         self.bytes_exchanged += count * 8 * (self.world - 1)
 
+    def _on_stream(self):
+        import contextlib
+
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def exchange(self, count: int) -> None:
         """Publish the first ``count`` records of the current log; apply what has arrived."""
+        with self._on_stream():
+            self._exchange(count)
+
+    def flush(self) -> None:
+        """Complete the exchange that is still in flight (end of a training call)."""
+        with self._on_stream():
+            if self._inflight is not None:
+                self._finish(*self._inflight)
+                self._inflight = None
+
+    def _exchange(self, count: int) -> None:
         if count > self.capacity:
             msg = f"delta log overflow: {count} records, capacity {self.capacity}"
             raise RuntimeError(msg)
@@ -101,13 +119,6 @@ class DeltaSync:
         if previous is not None:
             self._finish(*previous)
 
-    def flush(self) -> None:
-        """Complete the exchange that is still in flight (end of a training call)."""
-        if self._inflight is not None:
-            self._finish(*self._inflight)
-            self._inflight = None
-
-
 def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overlap: bool = True) -> DeltaSync:
     """Wire a :class:`DeltaSync` to a HIP engine living on the current CUDA device."""
     import ctypes as C
@@ -116,8 +127,11 @@ def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overl
 
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
-    # run the engine on torch's current stream so collectives and kernels are stream-ordered
-    _lib.check(lib.qe_set_stream(algorithm.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    # The engine and the collectives share ONE non-default torch stream, so kernels, all-gathers and
+    # delta scatter-adds are stream-ordered.  (Not the legacy default stream: its implicit
+    # synchronisation with every blocking stream would serialise the collective with the next chunk.)
+    stream = torch.cuda.Stream(device=dev)
+    _lib.check(lib.qe_set_stream(algorithm.handle, C.c_void_p(stream.cuda_stream)))
     capacity = sync_every * num_agents
 
     def apply_fn(entries, count):
@@ -126,4 +140,6 @@ def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overl
     def attach_fn(log):
         _lib.check(lib.qe_delta_log_attach(algorithm.handle, C.c_void_p(log.data_ptr()), capacity))
 
-    return DeltaSync(capacity, dev, apply_fn, attach_fn, group, overlap)
+    sync = DeltaSync(capacity, dev, apply_fn, attach_fn, group, overlap, stream)
+    stream.wait_stream(torch.cuda.current_stream())  # buffer initialisation ran on the current stream
+    return sync

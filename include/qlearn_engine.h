@@ -148,6 +148,14 @@ int qe_env_step(qe_env* env, const int32_t* actions, int32_t* obs, float* reward
  * trace_actions: optional host buffer steps*n int32 receiving every selected action (tests). */
 int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
                int32_t mode, int32_t* trace_actions, qe_rollout_stats* stats);
+/* Split form for pipelining: qe_rollout_begin only ENQUEUES a rollout (no host synchronisation) in
+ * one of two slots; qe_rollout_end waits for that slot and fetches its statistics and episode log
+ * (qe_episode_log then refers to it).  Beginning rollout k+1 before ending rollout k keeps the GPU
+ * busy while the host post-processes, and lets the RCCL exchange of chunk k overlap chunk k+1.
+ * qe_rollout == begin(slot 0) + end(slot 0). */
+int qe_rollout_begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
+                     int32_t mode, int32_t slot);
+int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats);
 /* qe_evaluate <- BaseRuntime.evaluate_steps / evaluate_episodes (base_runtime.py:293-384): greedy,
  * no learning.  Runs `steps` vector steps. */
 int qe_evaluate(qe_engine* e, qe_env* env, int64_t steps, qe_rollout_stats* stats);
