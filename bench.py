@@ -36,7 +36,10 @@ WORKLOADS = {
     "c4shard": {"agents": 8192, "states": 10_000_000, "actions": 32, "masked": False},
     "c5": {"agents": 1024, "states": 1_000_000, "actions": 64, "masked": True},
     "wide": {"agents": 262_144, "states": 10_000_000, "actions": 16, "masked": False},
+    # the environment of every number the reference publishes (benchmark_results/*.json)
+    "tictactoe": {"agents": 128, "states": 19_683, "actions": 9, "masked": True, "env": "tictactoe"},
 }
+PUBLISHED_TICTACTOE_SINGLE_THREAD_128 = 22_300.0  # benchmark_results/single_thread_128_agents.json
 SYNC_EVERY = 100  # BASELINE.json configs[3]: all-reduce of Q-deltas every 100 steps
 
 
@@ -54,11 +57,14 @@ def cpu_baseline(wl, budget_s: float = 12.0):
     pre-faulted, warm-up discarded)."""
     for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
         os.environ.setdefault(var, "1")  # throughput_benchmark.py:16-18
-    from oracle.envs import HashTabularEnv
+    from oracle.envs import HashTabularEnv, TicTacToeVecEnv
     from oracle.qlearn_oracle import OracleQLearning, OracleRuntime, OracleSchedule
 
     n = wl["agents"]
-    env = HashTabularEnv(n, wl["states"], wl["actions"], seed=1, masked=wl["masked"])
+    if wl.get("env") == "tictactoe":
+        env = TicTacToeVecEnv(n, seed=1)
+    else:
+        env = HashTabularEnv(n, wl["states"], wl["actions"], seed=1, masked=wl["masked"])
     algo = OracleQLearning(wl["states"], wl["actions"], 0.99, seed=0)
     algo.q_table.fill(0.0)  # pre-fault (BASELINE.md section 2)
     rt = OracleRuntime(algo, OracleSchedule("exponential", 0.1, 1e-5, 0.995),
@@ -81,6 +87,8 @@ def cpu_baseline(wl, budget_s: float = 12.0):
                   "oracle/qlearn_oracle.py (interpreted NumPy restatement of single_thread, fp64 table)",
     }
     try:
+        if wl.get("env") == "tictactoe":
+            raise ImportError  # the C restatement covers the hash environment only
         from oracle import c_oracle
 
         out["compiled_c_value"] = c_oracle.time_rollout(wl, seconds=3.0)
@@ -116,14 +124,17 @@ def main() -> None:
 
     from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
     from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
-    from dist_classicrl_amd.environments import HashTabularEnv
+    from dist_classicrl_amd.environments import HashTabularEnv, TicTacToeEnv
     from dist_classicrl_amd.schedules import ExponentialSchedule
 
     n = wl["agents"]
     algo = OptimalQLearningBase(wl["states"], wl["actions"], 0.99, seed=0, dtype=np.float32,
                                 device=local_rank)
-    env = HashTabularEnv(n, wl["states"], wl["actions"], seed=1, masked=wl["masked"],
-                         agent_offset=rank * n)
+    if wl.get("env") == "tictactoe":
+        env = TicTacToeEnv(n, seed=1, agent_offset=rank * n)
+    else:
+        env = HashTabularEnv(n, wl["states"], wl["actions"], seed=1, masked=wl["masked"],
+                             agent_offset=rank * n)
     rt = GpuRolloutQLearning(algo, ExponentialSchedule(0.1, 1e-5, 0.995),
                              ExponentialSchedule(1.0, 0.01, 0.995), learn_mode=args.mode)
     if use_dist:
@@ -186,7 +197,8 @@ def main() -> None:
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {n} agents/GPU, {wl['states']} states x {wl['actions']} actions, "
-                        f"fp32 Q-table, HashTabularEnv{' (masked)' if wl['masked'] else ''}, "
+                        f"fp32 Q-table, {'TicTacToeEnv' if wl.get('env') == 'tictactoe' else 'HashTabularEnv'}"
+                        f"{' (masked)' if wl['masked'] else ''}, "
                         f"learn={args.mode}, benchmark-default schedules",
             "agents_per_gpu": n, "states": wl["states"], "actions": wl["actions"],
             "sync_every": SYNC_EVERY if use_dist else None,
@@ -213,6 +225,9 @@ def main() -> None:
     if not args.no_cpu_baseline and n_gpus == 1:
         line["cpu_baseline"] = cpu_baseline(wl)
         line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    if args.workload == "tictactoe" and n_gpus == 1:
+        line["vs_reference_published_single_thread_128_agents_i7_11700K"] = (
+            line["value"] / PUBLISHED_TICTACTOE_SINGLE_THREAD_128)
     if use_dist:
         line["delta_sync"] = {"syncs": rt.delta_sync.syncs, "bytes_received_per_gpu": rt.delta_sync.bytes_exchanged}
     print(json.dumps(line))

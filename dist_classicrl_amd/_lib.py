@@ -19,7 +19,7 @@ LIB_PATH = Path(os.environ.get("QE_LIB_PATH") or Path(__file__).resolve().parent
 
 QE_F32, QE_F64 = 0, 1
 LEARN_ITER, LEARN_VEC = 0, 1
-ENV_HASH, ENV_GRID, ENV_BANDIT = 0, 1, 2
+ENV_HASH, ENV_GRID, ENV_BANDIT, ENV_TICTACTOE = 0, 1, 2, 3
 OPT_ROLLOUT_PATH = 0
 PATH_AUTO, PATH_STEPWISE, PATH_PERSISTENT = 0, 1, 2
 

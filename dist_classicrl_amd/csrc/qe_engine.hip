@@ -307,6 +307,8 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                 case 16: go(std::integral_constant<int, 16>{}); break;
                 default: go(std::integral_constant<int, 0>{}); break;
             }
+        } else if constexpr (std::is_same<Env, TttEnv>::value) {
+            go(std::integral_constant<int, 4>{});  // A = 9 -> ld = 12 -> 4 lanes per row
         } else {
             go(std::integral_constant<int, 1>{});  // GridLake (A = 4) and the bandit (A = 2): one lane per row
         }
@@ -395,6 +397,7 @@ int rollout_begin_dispatch(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t s
         case QE_ENV_HASH: return rollout_begin_impl<T, HashEnv>(e, env, sl, steps, mode, learn, trace);
         case QE_ENV_GRID: return rollout_begin_impl<T, GridEnv>(e, env, sl, steps, mode, learn, trace);
         case QE_ENV_BANDIT: return rollout_begin_impl<T, BanditEnv>(e, env, sl, steps, mode, learn, trace);
+        case QE_ENV_TICTACTOE: return rollout_begin_impl<T, TttEnv>(e, env, sl, steps, mode, learn, trace);
     }
     return fail(QE_ERR_INVALID, "unknown env kind %d", env->p.kind);
 }
@@ -405,6 +408,7 @@ int by_kind(int kind, F f) {
         case QE_ENV_HASH: return f(HashEnv{});
         case QE_ENV_GRID: return f(GridEnv{});
         case QE_ENV_BANDIT: return f(BanditEnv{});
+        case QE_ENV_TICTACTOE: return f(TttEnv{});
     }
     return fail(QE_ERR_INVALID, "unknown env kind %d", kind);
 }
@@ -695,6 +699,10 @@ int qe_env_create(qe_env** out, qe_engine* e, int64_t N, const qe_env_params* p)
             if (e->S != 1 || e->A != 2 || p->episode_len <= 0)
                 return fail(QE_ERR_INVALID, "bandit needs state_size 1, action_size 2, episode_len > 0");
             break;
+        case QE_ENV_TICTACTOE:
+            if (e->S != 19683 || e->A != 9)
+                return fail(QE_ERR_INVALID, "TicTacToe needs state_size 19683 (3^9) and action_size 9");
+            break;
         default: return fail(QE_ERR_INVALID, "unknown env kind %d", p->kind);
     }
     HIP_TRY(hipSetDevice(e->device));
@@ -803,7 +811,8 @@ int qe_env_step(qe_env* env, const int32_t* actions, int32_t* obs, float* reward
     int rc = by_kind(env->p.kind, [&](auto tag) {
         using Env = decltype(tag);
         hipLaunchKernelGGL(k_env_step<Env>, dim3(grid_for(env->N, 256)), dim3(256), 0, e->stream, ev, env->N,
-                           env->a.p, env->n.p, env->aux.p, env->r.p, env->term.p);
+                           env->a.p, env->n.p, env->aux.p, env->r.p, env->term.p,
+                           (unsigned long long)(e->step_ctr - 1));  // the step the latest selection consumed
         return QE_OK;
     });
     if (rc) return rc;

@@ -155,7 +155,7 @@ __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx
     T picked;
     const int act = select_action<LC>(row, valid, sub, c.L, explore, x.y, x.z, &picked);
     const int32_t n = p.n;
-    const Transition tr = Env::step(ev, i, n, p.aux, act);
+    const Transition tr = Env::step(ev, i, n, p.aux, act, c.step0 + (unsigned long long)t1);
     if (sub == 0) {
         if (!(flags & FLAG_NO_STAMPS)) {
             const int par1 = (int)(t1 & 1);
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_eval(Ctx<T> c, EnvCtx ev, long l
                                    STREAM_POLICY, c.seed_lo, c.seed_hi);
         T picked;
         const int act = select_action(row, Env::valid4(ev, i, n, sub), sub, c.L, false, x.y, x.z, &picked);
-        const Transition tr = Env::step(ev, i, n, aux, act);  // computed redundantly by every lane
+        const Transition tr = Env::step(ev, i, n, aux, act, step);  // computed redundantly by every lane
         acc += tr.reward;
         if (tr.terminated) {
             if (sub == 0) log_episode(c, t, i, acc);
@@ -987,11 +987,11 @@ __global__ void k_env_reset(EnvCtx ev, int64_t N, int32_t* obs, uint32_t* aux, f
 
 template <class Env>
 __global__ void k_env_step(EnvCtx ev, int64_t N, const int32_t* actions, int32_t* obs, uint32_t* aux,
-                           float* rewards, uint8_t* term) {
+                           float* rewards, uint8_t* term, unsigned long long step) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     uint32_t x = aux[i];
-    const Transition tr = Env::step(ev, i, obs[i], x, actions[i]);
+    const Transition tr = Env::step(ev, i, obs[i], x, actions[i], step);
     obs[i] = tr.next_obs; aux[i] = x; rewards[i] = tr.reward; term[i] = tr.terminated ? 1 : 0;
 }
 

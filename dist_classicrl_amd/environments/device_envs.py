@@ -150,3 +150,17 @@ class RiggedTwoArmedBanditVecEnv(DeviceVecEnv):
     def __init__(self, num_agents, episode_len=10):
         p = _lib.EnvParams(kind=self.kind, episode_len=int(episode_len))
         super().__init__(num_agents, 1, 2, p)
+
+
+class TicTacToeEnv(DeviceVecEnv):
+    """``n`` games of the reference's TicTacToe against a uniformly random opponent
+    (``environments/tiktaktoe_mod.py:67-237``) behind its Flatten-MultiDiscrete wrapper
+    (``wrappers/flatten_multidiscrete_wrapper.py:106-161``): 19 683 states, 9 masked actions --
+    the environment of every number the reference publishes (``docs/benchmarks.rst``)."""
+
+    kind = _lib.ENV_TICTACTOE
+    masked = True
+
+    def __init__(self, num_agents, seed=1, agent_offset=0):
+        p = _lib.EnvParams(kind=self.kind, masked=1, seed=int(seed) & 0xFFFFFFFF, agent_offset=int(agent_offset))
+        super().__init__(num_agents, 19683, 9, p)

@@ -55,13 +55,14 @@ enum qe_learn_mode { QE_LEARN_ITER = 0, QE_LEARN_VEC = 1 };
 enum qe_env_kind {
     QE_ENV_HASH = 0,  /* HashTabularEnv (build-defined synthetic MDP) */
     QE_ENV_GRID = 1,  /* GridLakeEnv: FrozenLake-style side x side grid */
-    QE_ENV_BANDIT = 2 /* environments/rigged_two_armed_bandit.py:55-80 */
+    QE_ENV_BANDIT = 2, /* environments/rigged_two_armed_bandit.py:55-80 */
+    QE_ENV_TICTACTOE = 3 /* environments/tiktaktoe_mod.py:67-237 + flatten_multidiscrete_wrapper.py:106-161 */
 };
 
 typedef struct qe_env_params {
     int32_t kind;          /* qe_env_kind */
-    int32_t masked;        /* HASH only: observations carry an action mask */
-    uint32_t seed;         /* HASH, GRID */
+    int32_t masked;        /* HASH: observations carry an action mask (TICTACTOE always does) */
+    uint32_t seed;         /* HASH, GRID, TICTACTOE */
     int32_t p_term_256;    /* HASH: terminate when (hash & 0xff) < p_term_256 */
     int32_t side;          /* GRID */
     int32_t episode_len;   /* BANDIT */

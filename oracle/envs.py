@@ -167,3 +167,109 @@ class RiggedBanditVecEnv(_VecEnvBase):
         self.t[terminated] = 0
         truncated = np.zeros(self.num_agents, dtype=bool)
         return self.obs.copy(), rewards, terminated, truncated, [{}] * self.num_agents
+
+
+C_TTT = 0x7F4A7C15
+LINES = (0b000000111, 0b000111000, 0b111000000, 0b001001001, 0b010010010, 0b100100100,
+         0b100010001, 0b001010100)  # bit i = board cell i (row-major)
+POW3 = 3 ** np.arange(8, -1, -1)  # cell 0 is the most significant base-3 digit (utils.py:12-29)
+
+
+def ttt_winner(mask1: int, mask2: int):
+    """``_check_winner`` (environments/tiktaktoe_mod.py:216-237) on occupancy bit masks."""
+    for line in LINES:
+        if mask1 & line == line:
+            return 1
+        if mask2 & line == line:
+            return 2
+    return None
+
+
+def ttt_encode(mask1: int, mask2: int) -> int:
+    """Flattened board (``_get_obs`` :199-214) through the mixed-radix encoder
+    (``utils.py:32-48`` with ``compute_radix([3]*9)`` = [6561, ..., 3, 1])."""
+    return int(sum((((mask1 >> i) & 1) + 2 * ((mask2 >> i) & 1)) * POW3[i] for i in range(9)))
+
+
+class TicTacToeVecEnv(_VecEnvBase):
+    """n copies of the reference's TicTacToe (environments/tiktaktoe_mod.py:67-237) behind the
+    Flatten-MultiDiscrete wrapper: observation = base-3 board id (S = 19683), 9 actions, action mask
+    = empty cells; the machine opponent plays uniformly random legal moves; reward +1 / -1 / 0;
+    never truncates.  Only the *source* of randomness differs from the reference (which uses a NumPy
+    Generator per env): three 32-bit words per (agent, vector step),
+
+        h0 = mix32(mix32(agent ^ seed ^ C_TTT) + step_lo * 0x9E3779B9 + step_hi)
+        machine reply = mulhi(h0, n_empty)-th empty cell
+        on reset: h1 = mix32(h0 ^ 0x68E31DA4) -> agent starts iff h1 & 1 == 0
+                  h2 = mix32(h0 ^ 0xB5297A4D) -> machine's opening cell = mulhi(h2, 9)
+
+    State per agent: cells holding mark 1 / mark 2 (two 9-bit masks) and the agent's mark."""
+
+    masked = True
+
+    def __init__(self, num_agents, seed=1, agent_offset=0):
+        self.num_agents = int(num_agents)
+        self.state_size = 19683
+        self.action_size = 9
+        self.seed = int(seed) & 0xFFFFFFFF
+        self.agent_ids = np.arange(agent_offset, agent_offset + self.num_agents, dtype=np.uint32)
+        self.m1 = np.zeros(self.num_agents, dtype=np.int64)
+        self.m2 = np.zeros(self.num_agents, dtype=np.int64)
+        self.agent_mark = np.ones(self.num_agents, dtype=np.int64)
+        self.step_index = 0  # vector step of the draw protocol the next step() belongs to
+
+    def _words(self, step):
+        inner = mix32(self.agent_ids ^ np.uint32(self.seed ^ C_TTT)).astype(np.uint64)
+        mixed = (inner + np.uint64(step & 0xFFFFFFFF) * np.uint64(0x9E3779B9) + np.uint64(step >> 32))
+        h0 = mix32(mixed & np.uint64(0xFFFFFFFF))
+        return h0, mix32(h0 ^ np.uint32(0x68E31DA4)), mix32(h0 ^ np.uint32(0xB5297A4D))
+
+    def _begin_episode(self, i, h1, h2):
+        self.m1[i] = self.m2[i] = 0
+        if (int(h1) & 1) == 0:  # agent starts: it plays mark 1 (:93-96)
+            self.agent_mark[i] = 1
+        else:  # machine starts with mark 1 on a uniformly random cell (:97-101)
+            self.agent_mark[i] = 2
+            self.m1[i] = 1 << int(mulhi32(h2, 9))
+
+    def _obs(self):
+        obs = np.array([ttt_encode(int(a), int(b)) for a, b in zip(self.m1, self.m2)], dtype=np.int32)
+        return {"observation": obs, "action_mask": self.action_masks(obs)}
+
+    def action_masks(self, obs):
+        digits = (np.asarray(obs, dtype=np.int64)[:, None] // POW3[None, :]) % 3
+        return (digits == 0).astype(np.int8)
+
+    def reset(self, seed=None, options=None):  # noqa: ARG002
+        if seed is not None:
+            self.seed = int(seed) & 0xFFFFFFFF
+        _, h1, h2 = self._words(0xFFFFFFFFFFFFFFFF)  # a step index no rollout reaches
+        for i in range(self.num_agents):
+            self._begin_episode(i, h1[i], h2[i])
+        return self._obs(), [{} for _ in range(self.num_agents)]
+
+    def step(self, actions):
+        h0, h1, h2 = self._words(self.step_index)
+        self.step_index += 1
+        n = self.num_agents
+        rewards = np.zeros(n, dtype=np.float32)
+        terminated = np.zeros(n, dtype=bool)
+        for i in range(n):
+            mine, theirs = (self.m1, self.m2) if self.agent_mark[i] == 1 else (self.m2, self.m1)
+            mine[i] |= 1 << int(actions[i])  # agent's move (:155-158)
+            full = lambda: (self.m1[i] | self.m2[i]) == 0x1FF  # noqa: E731
+            if ttt_winner(int(self.m1[i]), int(self.m2[i])) == self.agent_mark[i]:
+                rewards[i], terminated[i] = 1.0, True
+            elif full():
+                terminated[i] = True
+            else:  # machine's reply: uniformly random empty cell (:160-166, 173-190)
+                empty = [c for c in range(9) if not ((self.m1[i] | self.m2[i]) >> c) & 1]
+                theirs[i] |= 1 << empty[int(mulhi32(h0[i], len(empty)))]
+                if ttt_winner(int(self.m1[i]), int(self.m2[i])) is not None:
+                    rewards[i], terminated[i] = -1.0, True
+                elif full():
+                    terminated[i] = True
+            if terminated[i]:  # SAME_STEP autoreset
+                self._begin_episode(i, h1[i], h2[i])
+        truncated = np.zeros(n, dtype=bool)
+        return self._obs(), rewards, terminated, truncated, [{}] * n

@@ -32,7 +32,7 @@ from dist_classicrl.schedules.exponential_schedule import ExponentialSchedule  #
 from dist_classicrl.schedules.linear_schedule import LinearSchedule  # noqa: E402
 
 from oracle.draws import InjectedDraws  # noqa: E402
-from oracle.envs import GridLakeEnv, HashTabularEnv, RiggedBanditVecEnv  # noqa: E402
+from oracle.envs import GridLakeEnv, HashTabularEnv, RiggedBanditVecEnv, TicTacToeVecEnv  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
 sys.path.insert(0, str(OUT))
@@ -155,6 +155,8 @@ def _make_env(spec):
         return HashTabularEnv(n, S, A, seed=1, masked=masked)
     if kind == "grid":
         return GridLakeEnv(spec[1], side=spec[2], seed=1)
+    if kind == "ttt":
+        return TicTacToeVecEnv(spec[1], seed=1)
     return RiggedBanditVecEnv(spec[1], episode_len=spec[2])
 
 

@@ -50,4 +50,6 @@ TRACE_CASES = [
     ("hash_masked_a9_n64", ("hash", 64, 300, 9, True), 40, "f8", "const", "learn"),
     ("bandit_n4", ("bandit", 4, 5), 23, "f8", "kat", "learn"),
     ("bandit_n128", ("bandit", 128, 7), 30, "f4", "const", "learn"),
+    ("ttt_n64", ("ttt", 64), 60, "f8", "bench", "learn"),  # masked, A = 9: choose_masked_action (list) path
+    ("ttt_n128_f4", ("ttt", 128), 50, "f4", "const", "learn"),
 ]

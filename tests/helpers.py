@@ -6,7 +6,7 @@ from pathlib import Path
 
 import numpy as np
 
-from oracle.envs import GridLakeEnv, HashTabularEnv, RiggedBanditVecEnv
+from oracle.envs import GridLakeEnv, HashTabularEnv, RiggedBanditVecEnv, TicTacToeVecEnv
 from oracle.qlearn_oracle import OracleQLearning, OracleRuntime, OracleSchedule
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
@@ -26,6 +26,8 @@ TRACE_CASES = {
     "hash_masked_a9_n64": (("hash", 64, 300, 9, True), 40, "f8", "const", "iter"),
     "bandit_n4": (("bandit", 4, 5), 23, "f8", "kat", "iter"),
     "bandit_n128": (("bandit", 128, 7), 30, "f4", "const", "iter"),
+    "ttt_n64": (("ttt", 64), 60, "f8", "bench", "iter"),
+    "ttt_n128_f4": (("ttt", 128), 50, "f4", "const", "iter"),
 }
 
 
@@ -35,6 +37,8 @@ def make_oracle_env(spec):
         return HashTabularEnv(n, S, A, seed=1, masked=masked)
     if spec[0] == "grid":
         return GridLakeEnv(spec[1], side=spec[2], seed=1)
+    if spec[0] == "ttt":
+        return TicTacToeVecEnv(spec[1], seed=1)
     return RiggedBanditVecEnv(spec[1], episode_len=spec[2])
 
 

@@ -32,6 +32,8 @@ def make_device_env(spec):
         return envs.HashTabularEnv(n, S, A, seed=1, masked=masked)
     if spec[0] == "grid":
         return envs.GridLakeEnv(spec[1], side=spec[2], seed=1)
+    if spec[0] == "ttt":
+        return envs.TicTacToeEnv(spec[1], seed=1)
     return envs.RiggedTwoArmedBanditVecEnv(spec[1], episode_len=spec[2])
 
 
@@ -185,6 +187,9 @@ def test_rollout_matches_reference_golden(name, path):
         (("hash", 512, 700, 4, False), 40, "f4", "iter"),
         (("hash", 200, 50, 20, True), 40, "f4", "vec"),
         (("bandit", 128, 5), 25, "f4", "vec"),
+        (("ttt", 256), 80, "f4", "iter"),
+        (("ttt", 700), 40, "f8", "iter"),
+        (("ttt", 100), 60, "f4", "vec"),
     ],
 )
 @pytest.mark.parametrize("path", PATHS)
