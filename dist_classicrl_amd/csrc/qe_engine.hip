@@ -105,6 +105,7 @@ struct RolloutSlot {
     int n_samples = 0;
     int64_t steps = 0, N = 0, launches = 0;
     int32_t* trace_host = nullptr;
+    double* dbg = nullptr;  // env->vinc of the rollout in flight (diagnostic builds)
     void release() {
         if (ctrl) (void)hipFree(ctrl);
         ctrl = nullptr;
@@ -290,6 +291,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                     (long long)lanes);
     sl.launches = 0; sl.n_samples = 0; sl.steps = steps; sl.N = env->N; sl.persistent = persistent;
     sl.trace_host = trace_host;
+    sl.dbg = env->vinc.p;
     if (!persistent) HIP_TRY(hipMemsetAsync(sl.ctrl, 0, sizeof(Ctrl), e->stream));  // persistent kernel: in-kernel
     HIP_TRY(hipEventRecord(sl.ev0, e->stream));
     if (persistent) {
@@ -386,6 +388,18 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
             st->dominant_ms = ms; st->dominant_launches = 1; st->dominant_env_steps = sl.steps * sl.N;
         }
     }
+#ifdef QE_STAMPS
+    if (sl.persistent && getenv("QE_PRINT_STAMPS")) {
+        double seg[24];
+        (void)hipMemcpy(seg, sl.dbg, sizeof seg, hipMemcpyDeviceToHost);
+        const char* names[8] = {"inserts", "barrier", "row issue+classify", "philox", "update+account",
+                                "select+env", "extended+flush", "loop top"};
+        for (int k = 0; k < 8; ++k) fprintf(stderr, "  [stamps] %-20s %8.1f ns/step\n", names[k], seg[k] * 10.0 / sl.steps);
+        const char* sb[6] = {"sb list", "sb hash+stage", "sb cache+ranks", "sb rounds", "sb account", "sb select"};
+        for (int k = 0; k < 6; ++k) fprintf(stderr, "  [stamps] %-20s %8.1f ns/step\n", sb[k], seg[8 + k] * 10.0 / sl.steps);
+        fprintf(stderr, "  [stamps] slow_body calls %.0f, rounds/call %.2f\n", seg[15], seg[15] > 0 ? seg[14] / seg[15] : 0.0);
+    }
+#endif
     if (fin.error) return fail(QE_ERR_NO_DEVICE, "ordered path gave up (internal error %u)", fin.error);
     return QE_OK;
 }

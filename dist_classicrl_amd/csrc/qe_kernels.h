@@ -26,8 +26,9 @@ namespace qe {
 
 constexpr int FAST_BLOCK = 256;
 constexpr int SLOW_BLOCK = 1024;
-constexpr int SLOW_CAP = 2048;       // involved agents the LDS dataflow handles per step
-constexpr int SLOW_HASH = 8192;      // LDS hash slots (>= 2 * touches)
+constexpr int SLOW_CAP = 1024;       // involved agents the LDS dataflow handles per step
+constexpr int SLOW_HASH = 4096;      // LDS hash slots (>= 2 * touches)
+constexpr int SLOW_CACHE_BYTES = 48 * 1024;  // LDS row cache of the ordered path (step-wise kernels)
 
 constexpr int FLAG_LEARN = 1;
 constexpr int FLAG_SELECT = 2;
@@ -276,17 +277,27 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* wave_sums
 
 // LDS working set of the ordered path (one workgroup); CAP = involved agents handled by the
 // dataflow rounds, 4 * CAP hash slots (>= 2 x the touches).
-template <int CAP>
+template <int CAP, int CACHE_BYTES>
 struct SlowLdsT {
-    static constexpr int kCap = CAP, kHash = 4 * CAP;
+    static constexpr int kCap = CAP, kHash = 4 * CAP, kCacheBytes = CACHE_BYTES, kRowCap = 1024;
     int scan[18];
     int remaining;
+    int n_rows;     // distinct rows of this step's involved agents
+    int cache_ok;   // all of them fit the LDS row cache
+    int c_rowid[kRowCap];
+    short h_row[4 * CAP];  // hash slot -> row-cache index
+    // transitions of the involved agents, staged once so that a round touches LDS only
+    int a_agent[CAP], a_s[CAP], a_a[CAP], a_n[CAP];
+    float a_r[CAP];
+    unsigned char a_term[CAP];
+    alignas(16) unsigned char cache[CACHE_BYTES];
     int h_key[4 * CAP];
     int h_head[4 * CAP];
     int h_done[4 * CAP];
     int t_next[2 * CAP];
     short a_slot[2 * CAP];
-    short a_rank[2 * CAP];
+    short a_rank[2 * CAP];   // W touch: earlier readers of the row; R touch: earlier writers
+    short a_prev[CAP];       // latest earlier involved agent writing the SAME cell (-1 = none)
     unsigned char a_state[CAP];  // 0 = waiting, 1 = done, 2 = executed this round
 };
 
@@ -330,10 +341,48 @@ __device__ __forceinline__ void ordered_learn(const Ctx<T>& c, const EnvCtx& ev,
 // On return their transitions are learned, accounted (FLAG_ACCOUNT), their stamps cleared and --
 // with FLAG_SELECT -- their next transition (select(t+1), env.step(t+1), touches) is pending in the
 // global arrays.
-template <typename T, class Env, int CAP>
+// LDS-only barrier: orders LDS traffic without waiting for outstanding global accesses.
+__device__ __forceinline__ void barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// learn(t) for the involved agent staged at list position `pos`, entirely out of LDS (row cache lines
+// `is` / `in`); the new cell value is written to the cache and through to the table.
+template <typename T, class Env, class Lds>
+__device__ __forceinline__ void ordered_learn_cached(const Ctx<T>& c, const EnvCtx& ev, Lds& lds, int pos,
+                                                     int sub, long long t, const Hyper& h, T* cache, int is,
+                                                     int in) {
+    const int64_t i = lds.a_agent[pos];
+    const int32_t s = lds.a_s[pos], a = lds.a_a[pos], n = lds.a_n[pos];
+    const bool term = lds.a_term[pos] != 0;
+    T m = 0;
+    if (!term) {
+        Row4<T> row;
+        const T* src = cache + (int64_t)in * c.ld + 4 * sub;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row.v[j] = 4 * sub < c.ld ? src[j] : neg_inf<T>();
+        m = row_max_valid(row, Env::valid4(ev, i, n, sub), c.L);
+    }
+    if (sub == 0) {
+        T* cell = cache + (int64_t)is * c.ld + a;
+        T u;
+        const T q1 = Td<T>::apply(*cell, lds.a_r[pos], m, term, h, 0, &u);
+        *cell = q1;
+        c.q[(int64_t)s * c.ld + a] = q1;
+        log_delta(c, t, i, (int64_t)s * c.ld + a, u);
+    }
+}
+
+template <typename T, class Env, int CAP, int CACHE_BYTES>
 __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long long t, int M,
-                          SlowLdsT<CAP>& lds) {
+                          SlowLdsT<CAP, CACHE_BYTES>& lds) {
     constexpr int HASH = 4 * CAP;
+#ifdef QE_STAMPS
+    long long sb_last = wall_clock64();
+#define SB_STAMP(k) do { if (threadIdx.x == 0) { const long long _n = wall_clock64(); c.vinc[8 + (k)] += (double)(_n - sb_last); sb_last = _n; } } while (0)
+#else
+#define SB_STAMP(k) do { } while (0)
+#endif
     const int tid = threadIdx.x, BS = (int)blockDim.x;
     const int L = c.L;
     const int grp = tid >> c.lshift, sub = tid & (L - 1), ngrp = BS >> c.lshift;
@@ -355,6 +404,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
         base += total;
     }
     __syncthreads();
+    SB_STAMP(0);
 
     if (c.mode == 1) {
         // ---- VEC (learn_vec / np.add.at, q_learning_optimal.py:235-250,889-891): every involved
@@ -404,65 +454,171 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
     } else if (M <= CAP) {
         // ---- ITER: dataflow rounds; per shared row, touchers run in agent order ---------------
         for (int k = tid; k < HASH; k += BS) { lds.h_key[k] = -1; lds.h_head[k] = -1; lds.h_done[k] = 0; }
-        if (tid == 0) lds.remaining = M;
+        if (tid == 0) { lds.remaining = M; lds.n_rows = 0; lds.cache_ok = 1; }
+        const int row_cap = min((int)lds.kRowCap, (int)(CACHE_BYTES / (c.ld * (int)sizeof(T))));
+        T* cache = reinterpret_cast<T*>(lds.cache);
         __syncthreads();
         for (int id = tid; id < 2 * M; id += BS) {
             const int pos = id >> 1;
             const int64_t i = c.inv_list[pos];
             const LiveAgent<T> g = live_agent(c, i);
-            const bool need = (id & 1) == 0 || (!g.term && g.n != g.s);
+            const bool need = (id & 1) == 0 || !g.term;  // id even: W(row s); odd: R(row n), unless terminated
             int slot = -1;
             if (need) {
                 const int32_t rowid = (id & 1) ? g.n : g.s;
                 int h = (int)(mix32((uint32_t)rowid) & (HASH - 1));
                 for (;;) {
                     const int old = atomicCAS(&lds.h_key[h], -1, rowid);
-                    if (old == -1 || old == rowid) break;
+                    if (old == -1) {  // first toucher of this row: give it a row-cache line
+                        const int idx = atomicAdd(&lds.n_rows, 1);
+                        lds.h_row[h] = (short)(idx < row_cap ? idx : -1);
+                        if (idx < row_cap) lds.c_rowid[idx] = rowid; else lds.cache_ok = 0;
+                        break;
+                    }
+                    if (old == rowid) break;
                     h = (h + 1) & (HASH - 1);
                 }
                 slot = h;
                 lds.t_next[id] = atomicExch(&lds.h_head[h], id);
             }
             lds.a_slot[id] = (short)slot;
-            if ((id & 1) == 0) lds.a_state[pos] = 0;
+            if ((id & 1) == 0) {
+                lds.a_state[pos] = 0;
+                lds.a_agent[pos] = (int)i; lds.a_s[pos] = g.s; lds.a_a[pos] = g.a; lds.a_n[pos] = g.n;
+                lds.a_r[pos] = g.r; lds.a_term[pos] = g.term ? 1 : 0;
+            }
         }
         __syncthreads();
-        for (int id = tid; id < 2 * M; id += BS) {  // rank = lower-indexed touchers of the row
+        SB_STAMP(1);
+        const bool cached = lds.cache_ok != 0;
+        const Hyper hyper = make_hyper(c, c.lr[t]);
+        if (cached) {  // one parallel gather of every row the involved agents touch
+            const int nr = lds.n_rows;
+            for (int r = grp; r < nr; r += ngrp) {
+                const Row4<T> row = load_row4(c.q, lds.c_rowid[r], c.ld, sub);
+                if (4 * sub < c.ld) {
+                    T* dst = cache + (int64_t)r * c.ld + 4 * sub;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[j] = row.v[j];
+                }
+            }
+        }
+        // True dependencies of the sequential semantics, per row: a reader must follow every earlier
+        // WRITER of the row, a writer must follow every earlier READER of the row and the earlier
+        // writers of its own CELL.  Writers of different cells of one row commute.
+        for (int id = tid; id < 2 * M; id += BS) {
             const int slot = lds.a_slot[id];
-            int rank = 0;
-            if (slot >= 0)
-                for (int o = lds.h_head[slot]; o >= 0; o = lds.t_next[o]) rank += (o >> 1) < (id >> 1);
-            lds.a_rank[id] = (short)rank;
+            const int pos = id >> 1, is_read = id & 1;
+            int opposite = 0, prev = -1;
+            if (slot >= 0) {
+                const int my_a = lds.a_a[pos];
+                for (int o = lds.h_head[slot]; o >= 0; o = lds.t_next[o]) {
+                    const int opos = o >> 1;
+                    if (opos >= pos) continue;
+                    opposite += (o & 1) != is_read;
+                    if (!is_read && !(o & 1) && lds.a_a[opos] == my_a && opos > prev) prev = opos;
+                }
+            }
+            lds.a_rank[id] = (short)opposite;
+            if (!is_read) lds.a_prev[pos] = (short)prev;
         }
         __syncthreads();
+        SB_STAMP(2);
         // every round retires at least the lowest-indexed waiting agent, so M rounds always suffice;
         // the guard only keeps a logic error from hanging the GPU (reported through ctrl->error).
         int rounds = 0;
+        if (cached && M <= ngrp) {
+            // Common case: one lane group per involved agent.  Everything an agent needs is pulled
+            // into registers once; a round is then one LDS round trip for the readiness test, one for
+            // the cached row + cell, and ONE LDS barrier.  The finishing lane publishes its counters
+            // right after its cell write (LDS executes a wave's accesses in order), so a dependent that
+            // tests readiness later in the same round may already proceed.
+            const int pos = grp;
+            bool waiting = pos < M;
+            int ss = -1, sn = -1, rs = 0, rn = 0, prev = -1, is = -1, in = -1, a_act = 0;
+            int64_t ag = 0, cell_g = 0;
+            float r_ag = 0.0f;
+            bool term_ag = false;
+            uint32_t valid = 0u;
+            if (waiting) {
+                ss = lds.a_slot[2 * pos]; sn = lds.a_slot[2 * pos + 1];
+                rs = lds.a_rank[2 * pos]; rn = lds.a_rank[2 * pos + 1];
+                prev = lds.a_prev[pos];
+                is = lds.h_row[ss]; in = sn >= 0 ? (int)lds.h_row[sn] : is;
+                ag = lds.a_agent[pos]; a_act = lds.a_a[pos]; r_ag = lds.a_r[pos]; term_ag = lds.a_term[pos] != 0;
+                cell_g = (int64_t)lds.a_s[pos] * c.ld + a_act;
+                valid = Env::valid4(ev, ag, lds.a_n[pos], sub);
+            }
+            while (lds.remaining > 0 && rounds++ <= M) {
+                if (waiting) {
+                    const bool go = (lds.h_done[ss] & 0xFFFF) == rs && (prev < 0 || lds.a_state[prev] == 1) &&
+                                    (sn < 0 || (lds.h_done[sn] >> 16) == rn);
+                    if (go) {
+                        T m = 0;
+                        if (!term_ag) {
+                            Row4<T> row;
+                            const T* src = cache + (int64_t)in * c.ld + 4 * sub;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) row.v[j] = 4 * sub < c.ld ? src[j] : neg_inf<T>();
+                            m = row_max_valid(row, valid, L);
+                        }
+                        if (sub == 0) {
+                            T* cell = cache + (int64_t)is * c.ld + a_act;
+                            T u;
+                            const T q1 = Td<T>::apply(*cell, r_ag, m, term_ag, hyper, 0, &u);
+                            *cell = q1;
+                            c.q[cell_g] = q1;
+                            log_delta(c, t, ag, cell_g, u);
+                            lds.a_state[pos] = 1;
+                            atomicAdd(&lds.h_done[ss], 1 << 16);
+                            if (sn >= 0) atomicAdd(&lds.h_done[sn], 1);
+                            atomicSub(&lds.remaining, 1);
+                        }
+                        waiting = false;
+                    }
+                }
+                barrier_lds();
+            }
+        } else
         while (lds.remaining > 0 && rounds++ <= M) {
             for (int p0 = 0; p0 < M; p0 += ngrp) {
                 const int pos = p0 + grp;
                 bool go = false;
+                int ss = -1, sn = -1;
                 if (pos < M && lds.a_state[pos] == 0) {
-                    const int ss = lds.a_slot[2 * pos], sn = lds.a_slot[2 * pos + 1];
-                    go = lds.h_done[ss] == lds.a_rank[2 * pos] &&
-                         (sn < 0 || lds.h_done[sn] == lds.a_rank[2 * pos + 1]);
+                    ss = lds.a_slot[2 * pos]; sn = lds.a_slot[2 * pos + 1];
+                    const int prev = lds.a_prev[pos];
+                    // h_done: finished readers of the row in the low half, finished writers in the high half
+                    go = (lds.h_done[ss] & 0xFFFF) == lds.a_rank[2 * pos] &&
+                         (prev < 0 || lds.a_state[prev] == 1) &&
+                         (sn < 0 || (lds.h_done[sn] >> 16) == lds.a_rank[2 * pos + 1]);
                 }
                 if (go) {
-                    ordered_learn<T, Env>(c, ev, c.inv_list[pos], sub, t);
+                    if (cached) {
+                        const int is = lds.h_row[ss];
+                        ordered_learn_cached<T, Env>(c, ev, lds, pos, sub, t, hyper, cache, is,
+                                                     sn >= 0 ? (int)lds.h_row[sn] : is);
+                    } else {
+                        ordered_learn<T, Env>(c, ev, c.inv_list[pos], sub, t);
+                    }
                     if (sub == 0) lds.a_state[pos] = 2;
                 }
             }
-            __syncthreads();
+            if (cached) barrier_lds(); else __syncthreads();
             for (int pos = tid; pos < M; pos += BS) {
                 if (lds.a_state[pos] == 2) {
                     lds.a_state[pos] = 1;
-                    atomicAdd(&lds.h_done[lds.a_slot[2 * pos]], 1);
-                    if (lds.a_slot[2 * pos + 1] >= 0) atomicAdd(&lds.h_done[lds.a_slot[2 * pos + 1]], 1);
+                    atomicAdd(&lds.h_done[lds.a_slot[2 * pos]], 1 << 16);                           // a writer of row s
+                    if (lds.a_slot[2 * pos + 1] >= 0) atomicAdd(&lds.h_done[lds.a_slot[2 * pos + 1]], 1);  // a reader of row n
                     atomicSub(&lds.remaining, 1);
                 }
             }
-            __syncthreads();
+            if (cached) barrier_lds(); else __syncthreads();
         }
+        SB_STAMP(3);
+#ifdef QE_STAMPS
+        if (tid == 0) { c.vinc[14] += (double)rounds; c.vinc[15] += 1.0; }
+#endif
         if (tid == 0 && lds.remaining > 0) c.ctrl->error = 1u;
     } else {
         // ---- ITER, too many involved agents for LDS: strictly sequential on one wave ----------
@@ -486,6 +642,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
             c.stamps[2 * (int64_t)g.n + par] = 0ull;
         }
     }
+    SB_STAMP(4);
     if (flags & FLAG_SELECT) {
         for (int p0 = 0; p0 < M; p0 += ngrp) {
             const int pos = p0 + grp;
@@ -497,16 +654,17 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
             }
         }
     }
+    SB_STAMP(5);
 }
 
-using SlowLds = SlowLdsT<SLOW_CAP>;
+using SlowLds = SlowLdsT<SLOW_CAP, SLOW_CACHE_BYTES>;
 
 template <typename T, class Env>
 __global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, int flags) {
     __shared__ SlowLds lds;
     const long long t = c.ctrl->t_local;
     const int M = (int)c.ctrl->inv_count;
-    if (M > 0 && (flags & FLAG_LEARN)) slow_body<T, Env, SLOW_CAP>(c, ev, flags, t, M, lds);
+    if (M > 0 && (flags & FLAG_LEARN)) slow_body<T, Env, SLOW_CAP, SLOW_CACHE_BYTES>(c, ev, flags, t, M, lds);
     __syncthreads();
     if (threadIdx.x == 0) {
         c.ctrl->involved_total += (unsigned long long)M;
@@ -535,10 +693,11 @@ __global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, i
 constexpr int PERSIST_MAX_LANES = 1024;
 constexpr int PERSIST_MAX_AGENTS = 512;
 constexpr int CT_SLOTS = 2048;      // contention table slots (>= 2 x touches per step)
-constexpr int EP_STAGE = 2048;      // staged episode-log entries
+constexpr int EP_STAGE = 1024;      // staged episode-log entries
+constexpr int PERSIST_CACHE_BYTES = 20 * 1024;  // LDS row cache of the ordered path
 
 struct PersistLds {
-    SlowLdsT<PERSIST_MAX_AGENTS> slow;
+    SlowLdsT<PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES> slow;
     int ct_key[3][CT_SLOTS];
     unsigned ct_cnt[3][CT_SLOTS];
     int ct_min[3][CT_SLOTS];
@@ -576,6 +735,7 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
 #ifdef QE_STAMPS
     long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_last = wall_clock64();
+    if (threadIdx.x == 0) for (int k = 8; k < 24; ++k) c.vinc[k] = 0.0;
 #endif
     const int tid = threadIdx.x;
     const int L = LC ? LC : c.L;
@@ -750,7 +910,7 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                         lds.pending[i] = 0;
                     }
                     __syncthreads();
-                    slow_body<T, Env, PERSIST_MAX_AGENTS>(c, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
+                    slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES>(c, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
                     __syncthreads();
                 } else {
                     if (tid == 0) lds.n_rem = (unsigned)n_def;

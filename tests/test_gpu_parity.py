@@ -168,7 +168,7 @@ def test_rollout_matches_reference_golden(name, path):
     [
         (("hash", 1024, 5000, 16, False), 30, "f4", "iter"),
         (("hash", 1024, 5000, 16, False), 30, "f8", "iter"),
-        (("hash", 4096, 300, 8, False), 12, "f4", "iter"),  # > 2048 involved agents: sequential path
+        (("hash", 4096, 300, 8, False), 12, "f4", "iter"),  # > 1024 involved agents: sequential path
         (("hash", 512, 2000, 64, True), 20, "f4", "iter"),
         (("hash", 300, 100000, 32, False), 25, "f4", "iter"),
         (("hash", 700, 1000, 4, False), 25, "f8", "iter"),
