@@ -28,7 +28,7 @@ constexpr int FAST_BLOCK = 256;
 constexpr int SLOW_BLOCK = 1024;
 constexpr int SLOW_CAP = 1024;       // involved agents the LDS dataflow handles per step
 constexpr int SLOW_HASH = 4096;      // LDS hash slots (>= 2 * touches)
-constexpr int SLOW_CACHE_BYTES = 48 * 1024;  // LDS row cache of the ordered path (step-wise kernels)
+constexpr int SLOW_CACHE_BYTES = 40 * 1024;  // LDS row cache of the ordered path (step-wise kernels)
 
 constexpr int FLAG_LEARN = 1;
 constexpr int FLAG_SELECT = 2;
@@ -298,6 +298,9 @@ struct SlowLdsT {
     short a_slot[2 * CAP];
     short a_rank[2 * CAP];   // W touch: earlier readers of the row; R touch: earlier writers
     short a_prev[CAP];       // latest earlier involved agent writing the SAME cell (-1 = none)
+    short a_next[CAP];       // earliest later involved agent writing the SAME cell (-1 = none)
+    double a_m[CAP];         // pre-computed max_valid Q[n] of agents whose row n has no earlier writer
+    unsigned char a_mready[CAP];
     unsigned char a_state[CAP];  // 0 = waiting, 1 = done, 2 = executed this round
 };
 
@@ -484,6 +487,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
             lds.a_slot[id] = (short)slot;
             if ((id & 1) == 0) {
                 lds.a_state[pos] = 0;
+                lds.a_mready[pos] = 0;
                 lds.a_agent[pos] = (int)i; lds.a_s[pos] = g.s; lds.a_a[pos] = g.a; lds.a_n[pos] = g.n;
                 lds.a_r[pos] = g.r; lds.a_term[pos] = g.term ? 1 : 0;
             }
@@ -509,18 +513,23 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
         for (int id = tid; id < 2 * M; id += BS) {
             const int slot = lds.a_slot[id];
             const int pos = id >> 1, is_read = id & 1;
-            int opposite = 0, prev = -1;
+            int opposite = 0, prev = -1, next = 0x7FFF;
             if (slot >= 0) {
                 const int my_a = lds.a_a[pos];
                 for (int o = lds.h_head[slot]; o >= 0; o = lds.t_next[o]) {
                     const int opos = o >> 1;
-                    if (opos >= pos) continue;
+                    const bool same_cell = !is_read && !(o & 1) && lds.a_a[opos] == my_a;
+                    if (opos > pos) {
+                        if (same_cell && opos < next) next = opos;
+                        continue;
+                    }
+                    if (opos == pos) continue;
                     opposite += (o & 1) != is_read;
-                    if (!is_read && !(o & 1) && lds.a_a[opos] == my_a && opos > prev) prev = opos;
+                    if (same_cell && opos > prev) prev = opos;
                 }
             }
             lds.a_rank[id] = (short)opposite;
-            if (!is_read) lds.a_prev[pos] = (short)prev;
+            if (!is_read) { lds.a_prev[pos] = (short)prev; lds.a_next[pos] = (short)(next == 0x7FFF ? -1 : next); }
         }
         __syncthreads();
         SB_STAMP(2);
@@ -549,30 +558,75 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                 cell_g = (int64_t)lds.a_s[pos] * c.ld + a_act;
                 valid = Env::valid4(ev, ag, lds.a_n[pos], sub);
             }
+            // Round 0: targets that cannot be affected by any earlier involved writer are computed by
+            // everyone at once (the cached row is exactly what the sequential order would see).
+            T m_mine = 0;
+            bool m_known = false;
+            if (waiting && (term_ag || rn == 0)) {
+                if (!term_ag) {
+                    Row4<T> row;
+                    const T* src = cache + (int64_t)in * c.ld + 4 * sub;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) row.v[j] = 4 * sub < c.ld ? src[j] : neg_inf<T>();
+                    m_mine = row_max_valid(row, valid, L);
+                }
+                m_known = true;
+                if (sub == 0) { lds.a_m[pos] = (double)m_mine; lds.a_mready[pos] = 1; }
+            }
+            barrier_lds();
             while (lds.remaining > 0 && rounds++ <= M) {
                 if (waiting) {
-                    const bool go = (lds.h_done[ss] & 0xFFFF) == rs && (prev < 0 || lds.a_state[prev] == 1) &&
-                                    (sn < 0 || (lds.h_done[sn] >> 16) == rn);
+                    bool go = (lds.h_done[ss] & 0xFFFF) == rs && (prev < 0 || lds.a_state[prev] == 1) &&
+                              (sn < 0 || (lds.h_done[sn] >> 16) == rn);
+                    // Read AFTER the predecessor's flag: a run publishes its members last-to-first, so
+                    // whoever sees its predecessor finished also sees whether it was swept up itself.
+                    if (lds.a_state[pos] == 1) { waiting = false; go = false; }
                     if (go) {
-                        T m = 0;
-                        if (!term_ag) {
+                        T m = m_mine;
+                        if (!m_known && !term_ag) {  // every earlier writer of row n has finished by now
                             Row4<T> row;
                             const T* src = cache + (int64_t)in * c.ld + 4 * sub;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) row.v[j] = 4 * sub < c.ld ? src[j] : neg_inf<T>();
                             m = row_max_valid(row, valid, L);
                         }
-                        if (sub == 0) {
-                            T* cell = cache + (int64_t)is * c.ld + a_act;
+                        // The lane group then runs AHEAD along the chain of later agents that update the
+                        // SAME cell (many agents in one state taking the greedy action) as long as they
+                        // are "simple": target known from round 0 and no reader of row s in between.
+                        // The cell value stays in a register; nothing is published until the run ends,
+                        // so the successors' own lane groups cannot start meanwhile (no claiming needed).
+                        T* cell = cache + (int64_t)is * c.ld + a_act;
+                        T q_run = *cell;
+                        const int done_readers = lds.h_done[ss] & 0xFFFF;
+                        int cur = pos, cur_sn = sn, n_run = 0;
+                        int64_t cur_ag = ag;
+                        float cur_r = r_ag;
+                        bool cur_term = term_ag;
+                        for (;;) {
                             T u;
-                            const T q1 = Td<T>::apply(*cell, r_ag, m, term_ag, hyper, 0, &u);
-                            *cell = q1;
-                            c.q[cell_g] = q1;
-                            log_delta(c, t, ag, cell_g, u);
-                            lds.a_state[pos] = 1;
-                            atomicAdd(&lds.h_done[ss], 1 << 16);
-                            if (sn >= 0) atomicAdd(&lds.h_done[sn], 1);
-                            atomicSub(&lds.remaining, 1);
+                            q_run = Td<T>::apply(q_run, cur_r, m, cur_term, hyper, 0, &u);
+                            ++n_run;
+                            if (sub == 0) {
+                                log_delta(c, t, cur_ag, cell_g, u);
+                                if (cur_sn >= 0) atomicAdd(&lds.h_done[cur_sn], 1);  // a reader of its row n is done
+                            }
+                            const int nxt = lds.a_next[cur];
+                            if (nxt < 0 || !lds.a_mready[nxt] || lds.a_rank[2 * nxt] != done_readers) break;
+                            cur = nxt;
+                            cur_sn = lds.a_slot[2 * nxt + 1];
+                            cur_ag = lds.a_agent[nxt]; cur_r = lds.a_r[nxt]; cur_term = lds.a_term[nxt] != 0;
+                            m = (T)lds.a_m[nxt];
+                        }
+                        if (sub == 0) {
+                            *cell = q_run;
+                            c.q[cell_g] = q_run;
+                            // publish the whole run, last member first (see the readiness test above)
+                            for (int k = cur;; k = lds.a_prev[k]) {
+                                lds.a_state[k] = 1;
+                                if (k == pos) break;
+                            }
+                            atomicAdd(&lds.h_done[ss], n_run << 16);
+                            atomicSub(&lds.remaining, n_run);
                         }
                         waiting = false;
                     }
@@ -694,7 +748,7 @@ constexpr int PERSIST_MAX_LANES = 1024;
 constexpr int PERSIST_MAX_AGENTS = 512;
 constexpr int CT_SLOTS = 2048;      // contention table slots (>= 2 x touches per step)
 constexpr int EP_STAGE = 1024;      // staged episode-log entries
-constexpr int PERSIST_CACHE_BYTES = 20 * 1024;  // LDS row cache of the ordered path
+constexpr int PERSIST_CACHE_BYTES = 16 * 1024;  // LDS row cache of the ordered path
 
 struct PersistLds {
     SlowLdsT<PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES> slow;
