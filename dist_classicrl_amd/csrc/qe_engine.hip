@@ -389,7 +389,7 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         }
     }
 #ifdef QE_STAMPS
-    if (sl.persistent && getenv("QE_PRINT_STAMPS")) {
+    if (getenv("QE_PRINT_STAMPS")) {
         double seg[24];
         (void)hipMemcpy(seg, sl.dbg, sizeof seg, hipMemcpyDeviceToHost);
         const char* names[8] = {"inserts", "barrier", "row issue+classify", "philox", "update+account",

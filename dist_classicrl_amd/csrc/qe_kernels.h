@@ -718,6 +718,10 @@ __global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, i
     __shared__ SlowLds lds;
     const long long t = c.ctrl->t_local;
     const int M = (int)c.ctrl->inv_count;
+#ifdef QE_STAMPS
+    if (t == 0 && threadIdx.x == 0 && c.vinc) for (int k = 0; k < 24; ++k) c.vinc[k] = 0.0;
+    __syncthreads();
+#endif
     if (M > 0 && (flags & FLAG_LEARN)) slow_body<T, Env, SLOW_CAP, SLOW_CACHE_BYTES>(c, ev, flags, t, M, lds);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -805,6 +809,7 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
     p.s = 0; p.a = 0; p.pred = 0; p.r = 0.0f; p.term = false;
     float acc = c.acc[ii];
     unsigned long long deferred_total = 0, ep_base = 0;
+    U4 batch{0u, 0u, 0u, 0u};  // Philox blocks of the next steps, one per lane of the group
     // table slots of steps t-1 / t-2.  Lane 0 of a group owns the row-s slot; the row-n slot is owned
     // by lane 1 (slot) when the group has two or more lanes, by lane 0 (slot2) otherwise.
     int cur_slot = -1, prev_slot = -1, cur_slot2 = -1, prev_slot2 = -1;
@@ -909,10 +914,26 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
             if (LC != 1) cls = __shfl(cls, 0, L);
         }
         QE_STAMP(2);
-        // ---- Philox draws of select(t+1): independent of memory, computed under the row gather ---
-        const unsigned long long step1 = c.step0 + (unsigned long long)(t + 1);
-        const U4 x = philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)step1, (uint32_t)(step1 >> 32),
-                                   STREAM_POLICY, c.seed_lo, c.seed_hi);
+        // ---- Philox draws of select(t+1): independent of memory, computed under the row gather.
+        // A group of LB lanes serves one agent, so every LB-th step each lane evaluates the block of a
+        // DIFFERENT upcoming step (lane k: step t+1+k); the other steps just fetch their block from the
+        // lane that holds it.  One Philox evaluation per LB steps instead of one per step.
+        constexpr int LB = LC >= 4 ? 4 : (LC == 2 ? 2 : 1);
+        U4 x;
+        if (LB == 1) {
+            const unsigned long long step1 = c.step0 + (unsigned long long)(t + 1);
+            x = philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)step1, (uint32_t)(step1 >> 32),
+                              STREAM_POLICY, c.seed_lo, c.seed_hi);
+        } else {
+            const int phase = (int)(t & (LB - 1));
+            if (phase == 0) {
+                const unsigned long long stepk = c.step0 + (unsigned long long)(t + 1) + (unsigned)(sub & (LB - 1));
+                batch = philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)stepk, (uint32_t)(stepk >> 32),
+                                      STREAM_POLICY, c.seed_lo, c.seed_hi);
+            }
+            x.x = __shfl(batch.x, phase, LB); x.y = __shfl(batch.y, phase, LB); x.z = __shfl(batch.z, phase, LB);
+            x.w = 0u;
+        }
         const float r_t = p.r;
         const bool term_t = p.term;
         QE_STAMP(3);
