@@ -93,8 +93,11 @@ class OptimalQLearningBase:
 
     def set_rollout_path(self, path: str) -> None:
         """Tuning knob, never changes results: ``"auto"``, ``"stepwise"`` (one kernel pair per vector
-        step) or ``"persistent"`` (one launch per rollout; needs agents x lanes-per-row <= 1024)."""
-        code = {"auto": _lib.PATH_AUTO, "stepwise": _lib.PATH_STEPWISE, "persistent": _lib.PATH_PERSISTENT}[path]
+        step), ``"persistent"`` (one launch per rollout; needs <= 512 agents and agents x lanes-per-row
+        <= 1024) or ``"wide"`` (step-wise, the ordered path spread over the whole chip; automatic
+        from 2048 agents)."""
+        code = {"auto": _lib.PATH_AUTO, "stepwise": _lib.PATH_STEPWISE, "persistent": _lib.PATH_PERSISTENT,
+                "wide": _lib.PATH_WIDE}[path]
         _lib.check(self._lib.qe_set_option(self._h, _lib.OPT_ROLLOUT_PATH, code))
 
     @property

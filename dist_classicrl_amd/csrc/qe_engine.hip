@@ -134,6 +134,7 @@ struct qe_engine {
     void* q = nullptr;
     unsigned long long* stamps = nullptr;
     Ctrl* ctrl = nullptr;
+    uint32_t* tok = nullptr;  // [2][S] wide-mode tokens, allocated on first use, all TOK_INF at rest
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // schedules
     DevBuf<unsigned long long> thr;
@@ -165,7 +166,7 @@ struct qe_env {
     DevBuf<int32_t> s, a, n, list;
     DevBuf<float> r, acc;
     DevBuf<uint8_t> term, pred, masks;
-    DevBuf<uint32_t> aux, bitmap;
+    DevBuf<uint32_t> aux, bitmap, adv_bitmap;
     DevBuf<double> vinc;
 };
 
@@ -254,18 +255,27 @@ void pack_masks(const uint8_t* masks, int64_t n, int A, std::vector<uint32_t>& o
 
 constexpr int MAX_SAMPLES = 256;
 
+constexpr int TOKEN_ROUNDS = 4;  // chip-wide rounds before the single-workgroup clean-up (wide mode)
+
 template <typename T, class Env>
 void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow,
                  int sample = -1) {
+    const dim3 grid(grid_for(c.N * c.L, FAST_BLOCK)), block(FAST_BLOCK);
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample], e->stream);
-    hipLaunchKernelGGL((k_step_fast<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK),
-                       0, e->stream, c, ev, flags);
+    hipLaunchKernelGGL((k_step_fast<T, Env>), grid, block, 0, e->stream, c, ev, flags);
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
     ++sl.launches;
-    if (slow) {
-        hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
-        ++sl.launches;
+    if (!slow) return;
+    if (c.tok) {  // wide mode: token rounds on the whole chip, clean-up, postponed selections
+        for (int r = 0; r < TOKEN_ROUNDS; ++r)
+            hipLaunchKernelGGL((k_token_round<T, Env>), grid, block, 0, e->stream, c, ev, flags, r);
+        hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
+        hipLaunchKernelGGL((k_advance<T, Env>), grid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1);
+        sl.launches += TOKEN_ROUNDS + 2;
+        return;
     }
+    hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
+    ++sl.launches;
 }
 
 // Enqueue one rollout (no host synchronisation): schedules, control block, kernels, events.
@@ -285,10 +295,22 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         c.dlog = e->dlog; c.dlog_base = e->dlog_count; c.dlog_cap = e->dlog_cap;
     }
     const int64_t lanes = env->N * e->L;
-    const bool persistent = learn && lanes <= PERSIST_MAX_LANES && env->N <= PERSIST_MAX_AGENTS && e->opt_path != 1;
+    const bool persistent = learn && lanes <= PERSIST_MAX_LANES && env->N <= PERSIST_MAX_AGENTS &&
+                            (e->opt_path == 0 || e->opt_path == 2);
     if (learn && e->opt_path == 2 && !persistent)
         return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and num_agents * lanes_per_row <= 1024 (have %lld lanes)",
                     (long long)lanes);
+    // wide mode: exact sequential updates, many agents, ordered path spread over the chip
+    const bool wide = learn && !persistent && mode == QE_LEARN_ITER &&
+                      (e->opt_path == 3 || (e->opt_path == 0 && env->N >= 2048));
+    if (wide) {
+        if (!e->tok) {
+            HIP_TRY(hipMalloc((void**)&e->tok, (size_t)e->S * 2 * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(e->tok, 0xFF, (size_t)e->S * 2 * sizeof(uint32_t), e->stream));
+        }
+        c.tok = e->tok;
+        c.adv_bitmap = env->adv_bitmap.p;
+    }
     sl.launches = 0; sl.n_samples = 0; sl.steps = steps; sl.N = env->N; sl.persistent = persistent;
     sl.trace_host = trace_host;
     sl.dbg = env->vinc.p;
@@ -491,6 +513,7 @@ int qe_destroy(qe_engine* e) {
     if (e->q) (void)hipFree(e->q);
     if (e->stamps) (void)hipFree(e->stamps);
     if (e->ctrl) (void)hipFree(e->ctrl);
+    if (e->tok) (void)hipFree(e->tok);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     e->slots[0].release(); e->slots[1].release();
@@ -510,7 +533,7 @@ int qe_synchronize(qe_engine* e) {
 }
 
 int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
-    if (option == QE_OPT_ROLLOUT_PATH && value >= 0 && value <= 2) { e->opt_path = (int)value; return QE_OK; }
+    if (option == QE_OPT_ROLLOUT_PATH && value >= 0 && value <= 3) { e->opt_path = (int)value; return QE_OK; }
     return fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 
@@ -735,6 +758,8 @@ int qe_env_create(qe_env** out, qe_engine* e, int64_t N, const qe_env_params* p)
     if (err == hipSuccess) err = env->vinc.ensure(un);
     if (err == hipSuccess) err = env->bitmap.ensure((un + 31) / 32);
     if (err == hipSuccess) err = hipMemsetAsync(env->bitmap.p, 0, env->bitmap.cap * 4, e->stream);
+    if (err == hipSuccess) err = env->adv_bitmap.ensure((un + 31) / 32);
+    if (err == hipSuccess) err = hipMemsetAsync(env->adv_bitmap.p, 0, env->adv_bitmap.cap * 4, e->stream);
     if (err != hipSuccess) {
         qe_env_destroy(env);
         return fail(QE_ERR_OOM, "env allocation failed: %s", hipGetErrorString(err));
@@ -749,7 +774,7 @@ int qe_env_destroy(qe_env* env) {
     (void)hipStreamSynchronize(env->e->stream);
     env->s.release(); env->a.release(); env->n.release(); env->list.release(); env->r.release();
     env->acc.release(); env->term.release(); env->pred.release(); env->aux.release();
-    env->bitmap.release(); env->masks.release(); env->vinc.release();
+    env->bitmap.release(); env->adv_bitmap.release(); env->masks.release(); env->vinc.release();
     delete env;
     return QE_OK;
 }

@@ -36,6 +36,8 @@ constexpr int FLAG_DETERMINISTIC = 4;  // greedy selection (evaluate_*: explorat
 constexpr int FLAG_PRED_FROM_TABLE = 8;  // qe_learn: Q[s,a] is not carried, read it
 constexpr int FLAG_ACCOUNT = 16;         // episode-return bookkeeping (rollouts; not qe_learn)
 constexpr int FLAG_NO_STAMPS = 32;       // persistent kernel: contention is tracked in LDS instead
+constexpr int FLAG_T_MINUS_1 = 64;       // the step counter has already been advanced (k_advance)
+constexpr uint32_t TOK_INF = 0xFFFFFFFFu;
 
 struct Ctrl {
     long long t_local;                   // vector step inside the current rollout call
@@ -60,6 +62,8 @@ struct Ctx {
     uint32_t* inv_bitmap;   // ceil(N/32) words
     int32_t* inv_list;      // N
     double* vinc;           // N: VEC-mode increments of involved agents
+    uint32_t* tok;          // [2][S] lowest pending agent per row (wide mode; nullptr otherwise)
+    uint32_t* adv_bitmap;   // agents whose selection of step t+1 waits for all updates of step t
     Ctrl* ctrl;
     // agent state: pending transition (s, a, pred, r, term) and current observation n
     int32_t* s;
@@ -214,6 +218,11 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
             if (sub == 0) {
                 atomicOr(&c.inv_bitmap[i >> 5], 1u << (i & 31));
                 atomicAdd(&c.ctrl->inv_count, 1u);
+                if (c.tok) {  // wide mode: enter the token rounds (k_token_round) and the late selection
+                    atomicOr(&c.adv_bitmap[i >> 5], 1u << (i & 31));
+                    atomicMin(&c.tok[s], (uint32_t)i);
+                    if (c.term[i] == 0 && n != s) atomicMin(&c.tok[n], (uint32_t)i);
+                }
             }
             return;
         }
@@ -695,6 +704,10 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
             c.stamps[2 * (int64_t)g.s + par] = 0ull;
             c.stamps[2 * (int64_t)g.n + par] = 0ull;
         }
+        if (c.tok) {  // whatever the token rounds left posted for these agents
+            c.tok[g.s] = TOK_INF; c.tok[c.S + g.s] = TOK_INF;
+            c.tok[g.n] = TOK_INF; c.tok[c.S + g.n] = TOK_INF;
+        }
     }
     SB_STAMP(4);
     if (flags & FLAG_SELECT) {
@@ -1050,6 +1063,78 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
         c.ctrl->involved_total = deferred_total;
         c.ctrl->ep_count = ep_base;
         c.ctrl->t_local = steps;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Wide mode (many agents): the involved agents of a step are first worked off by token rounds that
+// run on the whole chip.  In round r every pending agent looks at the token of its rows (the lowest
+// pending agent index posted for the row, two alternating arrays): it updates iff it holds the token
+// of ALL its rows -- so per row the touchers run in agent order, the exact sequential semantics --
+// otherwise it posts itself for the next round.  No two agents that update in the same round share a
+// row.  After a fixed number of rounds the single-workgroup slow_body finishes whatever is left
+// (long chains), and k_advance performs the postponed selections once every update of the step is in.
+template <typename T, class Env>
+__global__ __launch_bounds__(FAST_BLOCK) void k_token_round(Ctx<T> c, EnvCtx ev, int flags, int round) {
+    const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
+    const int64_t i = gl >> c.lshift;
+    const int sub = (int)(gl & (c.L - 1));
+    if (i >= c.N) return;
+    if (!((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u)) return;  // not pending (whole lane group leaves)
+    const long long t = c.ctrl->t_local;
+    const int32_t s = c.s[i], a = c.a[i], n = c.n[i];
+    const bool term = c.term[i] != 0;
+    const bool need_n = !term && n != s;
+    uint32_t* cur = c.tok + (int64_t)(round & 1) * c.S;
+    uint32_t* nxt = c.tok + (int64_t)((round & 1) ^ 1) * c.S;
+    const uint32_t ts = cur[s];
+    const uint32_t tn = need_n ? cur[n] : (uint32_t)i;
+    // whoever holds a token takes it off the board (the others only compare it with their own index)
+    if (sub == 0) {
+        if (ts == (uint32_t)i) cur[s] = TOK_INF;
+        if (need_n && tn == (uint32_t)i) cur[n] = TOK_INF;
+    }
+    if (ts == (uint32_t)i && tn == (uint32_t)i) {
+        T m = 0;
+        if (!term) {
+            const Row4<T> row = load_row4(c.q, n, c.ld, sub);
+            m = row_max_valid(row, Env::valid4(ev, i, n, sub), c.L);
+        }
+        if (sub == 0) {
+            const int64_t cell = (int64_t)s * c.ld + a;
+            T u;
+            c.q[cell] = Td<T>::apply(c.q[cell], c.r[i], m, term, make_hyper(c, c.lr[t]), 0, &u);
+            log_delta(c, t, i, cell, u);
+            if (flags & FLAG_ACCOUNT) account(c, t, i, c.r[i], term);
+            atomicAnd(&c.inv_bitmap[i >> 5], ~(1u << (i & 31)));
+            atomicSub(&c.ctrl->inv_count, 1u);
+        }
+    } else if (sub == 0) {
+        atomicMin(&nxt[s], (uint32_t)i);
+        if (need_n) atomicMin(&nxt[n], (uint32_t)i);
+    }
+}
+
+// Postponed selections of wide mode: every agent that was involved in step t selects its action of
+// step t+1 only now, when all updates of step t are in the table (also clears its stamps).
+template <typename T, class Env>
+__global__ __launch_bounds__(FAST_BLOCK) void k_advance(Ctx<T> c, EnvCtx ev, int flags) {
+    const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
+    const int64_t i = gl >> c.lshift;
+    const int sub = (int)(gl & (c.L - 1));
+    if (i >= c.N) return;
+    if (!((c.adv_bitmap[i >> 5] >> (i & 31)) & 1u)) return;
+    const long long t = c.ctrl->t_local - ((flags & FLAG_T_MINUS_1) ? 1 : 0);
+    const int32_t s = c.s[i], n = c.n[i];
+    if (sub == 0) {
+        const int par = (int)(t & 1);
+        c.stamps[2 * (int64_t)s + par] = 0ull;
+        c.stamps[2 * (int64_t)n + par] = 0ull;
+        atomicAnd(&c.adv_bitmap[i >> 5], ~(1u << (i & 31)));
+    }
+    if (flags & FLAG_SELECT) {
+        Row4<T> row = load_row4(c.q, n, c.ld, sub);
+        advance_agent<T, Env>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
     }
 }
 

@@ -93,7 +93,8 @@ int qe_synchronize(qe_engine* e);
 /* Use the caller's HIP stream (hipStream_t as void*) instead of the engine's own. */
 int qe_set_stream(qe_engine* e, void* hip_stream);
 /* Tuning knobs (never change results).  QE_OPT_ROLLOUT_PATH: 0 = automatic, 1 = one kernel pair per
- * vector step, 2 = persistent single-workgroup kernel (needs num_agents * lanes_per_row <= 1024). */
+ * vector step, 2 = persistent single-workgroup kernel (needs num_agents <= 512 and num_agents *
+ * lanes_per_row <= 1024), 3 = step-wise with chip-wide token rounds for the ordered path ("wide"). */
 enum qe_option { QE_OPT_ROLLOUT_PATH = 0 };
 int qe_set_option(qe_engine* e, int32_t option, int64_t value);
 
