@@ -377,14 +377,38 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
     const Ctrl fin = *sl.h_ctrl.p;
-    // episode log -> host, sorted by (step, agent) = append order of base_runtime.py:218-221
-    const long long got = std::min<long long>((long long)fin.ep_count, e->ep_cap);
+    // episode log -> host, sorted by (step, agent) = append order of base_runtime.py:218-221.
+    // The persistent kernel writes a linear log (ep_count entries); the step-wise kernels write 64
+    // segments of ep_cap/64 entries each (ep_seg[] counts).
+    const long long seg_cap = e->ep_cap >> 6;
+    long long total = 0, got = 0;
+    long long seg_got[64];
+    if (sl.persistent) {
+        total = (long long)fin.ep_count;
+        got = std::min<long long>(total, e->ep_cap);
+    } else {
+        for (int k = 0; k < 64; ++k) {
+            total += fin.ep_seg[k];
+            seg_got[k] = std::min<long long>(fin.ep_seg[k], seg_cap);
+            got += seg_got[k];
+        }
+    }
     e->ep_host.resize((size_t)got);
     if (got) {
         HIP_TRY(sl.h_key.ensure((size_t)got));
         HIP_TRY(sl.h_ret.ensure((size_t)got));
-        HIP_TRY(hipMemcpyAsync(sl.h_key.p, sl.ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
-        HIP_TRY(hipMemcpyAsync(sl.h_ret.p, sl.ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost, e->copy_stream));
+        if (sl.persistent) {
+            HIP_TRY(hipMemcpyAsync(sl.h_key.p, sl.ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
+            HIP_TRY(hipMemcpyAsync(sl.h_ret.p, sl.ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost, e->copy_stream));
+        } else {
+            long long off = 0;
+            for (int k = 0; k < 64; ++k) {
+                if (!seg_got[k]) continue;
+                HIP_TRY(hipMemcpyAsync(sl.h_key.p + off, sl.ep_key.p + k * seg_cap, seg_got[k] * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
+                HIP_TRY(hipMemcpyAsync(sl.h_ret.p + off, sl.ep_ret.p + k * seg_cap, seg_got[k] * sizeof(float), hipMemcpyDeviceToHost, e->copy_stream));
+                off += seg_got[k];
+            }
+        }
         HIP_TRY(hipStreamSynchronize(e->copy_stream));
         for (long long k = 0; k < got; ++k) e->ep_host[(size_t)k] = {sl.h_key.p[k], sl.h_ret.p[k]};
     }
@@ -396,9 +420,9 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
     }
     if (st) {
         memset(st, 0, sizeof *st);
-        st->kernel_ms = ms; st->launches = sl.launches; st->episodes = (int64_t)fin.ep_count;
+        st->kernel_ms = ms; st->launches = sl.launches; st->episodes = (int64_t)total;
         st->involved = (int64_t)fin.involved_total;
-        st->episodes_dropped = (int64_t)fin.ep_count - got;
+        st->episodes_dropped = (int64_t)(total - got);
         for (int k = 0; k < sl.n_samples; ++k) {
             float one = 0;
             if (hipEventElapsedTime(&one, sl.sample_ev[2 * k], sl.sample_ev[2 * k + 1]) == hipSuccess)

@@ -43,7 +43,8 @@ struct Ctrl {
     long long t_local;                   // vector step inside the current rollout call
     unsigned int inv_count;              // involved agents of the step being processed
     unsigned int error;                  // set by a kernel that had to give up (never expected)
-    unsigned long long ep_count;         // episode-log entries written
+    unsigned long long ep_count;         // episode-log entries written (persistent kernel: linear log)
+    unsigned int ep_seg[64];             // entries per log segment (step-wise kernels: segmented log)
     unsigned long long involved_total;   // statistics
 };
 
@@ -113,10 +114,15 @@ __device__ __forceinline__ Hyper make_hyper(const Ctx<T>& c, double lr) {
 
 template <typename T>
 __device__ __forceinline__ void log_episode(const Ctx<T>& c, long long t, int64_t i, float ret) {
-    const unsigned long long p = atomicAdd(&c.ctrl->ep_count, 1ull);
-    if ((long long)p < c.ep_cap) {
-        c.ep_key[p] = ((unsigned long long)t << 32) | (unsigned long long)i;
-        c.ep_ret[p] = ret;
+    // 64 log segments, chosen by (agent + step): thousands of agents finishing an episode in the same
+    // step would otherwise serialise on one counter word (~90 returning atomics per microsecond).
+    const unsigned seg = (unsigned)(i + t) & 63u;
+    const long long seg_cap = c.ep_cap >> 6;
+    const unsigned p = atomicAdd(&c.ctrl->ep_seg[seg], 1u);
+    if ((long long)p < seg_cap) {
+        const long long at = (long long)seg * seg_cap + p;
+        c.ep_key[at] = ((unsigned long long)t << 32) | (unsigned long long)i;
+        c.ep_ret[at] = ret;
     }
 }
 
@@ -217,7 +223,8 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
         if (contested(cs) || (n != s && contested(cn))) {  // shared row: defer to the ordered path
             if (sub == 0) {
                 atomicOr(&c.inv_bitmap[i >> 5], 1u << (i & 31));
-                atomicAdd(&c.ctrl->inv_count, 1u);
+                c.ctrl->inv_count = 1u;  // "some agent is involved" flag (a shared counter would serialise
+                                         // tens of thousands of same-address atomics at large N)
                 if (c.tok) {  // wide mode: enter the token rounds (k_token_round) and the late selection
                     atomicOr(&c.adv_bitmap[i >> 5], 1u << (i & 31));
                     atomicMin(&c.tok[s], (uint32_t)i);
@@ -385,6 +392,30 @@ __device__ __forceinline__ void ordered_learn_cached(const Ctx<T>& c, const EnvC
     }
 }
 
+// Ordered list of the involved agents (ascending agent index) from the bitmap, which is cleared on
+// the way; every thread of the workgroup calls it and gets the count.
+template <typename T>
+__device__ int build_involved_list(const Ctx<T>& c, int* scan) {
+    const int tid = threadIdx.x, BS = (int)blockDim.x;
+    const int W = (int)((c.N + 31) >> 5);
+    int base = 0;
+    for (int w0 = 0; w0 < W; w0 += BS) {
+        const int w = w0 + tid;
+        uint32_t word = w < W ? load_live(c.inv_bitmap + w) : 0u;
+        int total;
+        int p = base + block_excl_scan(__popc(word), &total, scan);
+        while (word) {
+            const int b = __ffs(word) - 1;
+            c.inv_list[p++] = w * 32 + b;
+            word &= word - 1u;
+        }
+        if (w < W && total) store_live(c.inv_bitmap + w, 0u);
+        base += total;
+    }
+    __syncthreads();
+    return base;
+}
+
 template <typename T, class Env, int CAP, int CACHE_BYTES>
 __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long long t, int M,
                           SlowLdsT<CAP, CACHE_BYTES>& lds) {
@@ -399,23 +430,6 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
     const int L = c.L;
     const int grp = tid >> c.lshift, sub = tid & (L - 1), ngrp = BS >> c.lshift;
 
-    // ---- ordered list of involved agents from the bitmap (ascending agent index) --------------
-    const int W = (int)((c.N + 31) >> 5);
-    int base = 0;
-    for (int w0 = 0; w0 < W; w0 += BS) {
-        const int w = w0 + tid;
-        uint32_t word = w < W ? load_live(c.inv_bitmap + w) : 0u;
-        int total;
-        int p = base + block_excl_scan(__popc(word), &total, lds.scan);
-        while (word) {
-            const int b = __ffs(word) - 1;
-            c.inv_list[p++] = w * 32 + b;
-            word &= word - 1u;
-        }
-        if (w < W) store_live(c.inv_bitmap + w, 0u);
-        base += total;
-    }
-    __syncthreads();
     SB_STAMP(0);
 
     if (c.mode == 1) {
@@ -730,7 +744,8 @@ template <typename T, class Env>
 __global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, int flags) {
     __shared__ SlowLds lds;
     const long long t = c.ctrl->t_local;
-    const int M = (int)c.ctrl->inv_count;
+    int M = 0;
+    if (c.ctrl->inv_count != 0u && (flags & FLAG_LEARN)) M = build_involved_list(c, lds.scan);
 #ifdef QE_STAMPS
     if (t == 0 && threadIdx.x == 0 && c.vinc) for (int k = 0; k < 24; ++k) c.vinc[k] = 0.0;
     __syncthreads();
@@ -998,6 +1013,7 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                         lds.pending[i] = 0;
                     }
                     __syncthreads();
+                    (void)build_involved_list(c, lds.slow.scan);  // == n_def agents
                     slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES>(c, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
                     __syncthreads();
                 } else {
@@ -1107,7 +1123,6 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_token_round(Ctx<T> c, EnvCtx ev,
             log_delta(c, t, i, cell, u);
             if (flags & FLAG_ACCOUNT) account(c, t, i, c.r[i], term);
             atomicAnd(&c.inv_bitmap[i >> 5], ~(1u << (i & 31)));
-            atomicSub(&c.ctrl->inv_count, 1u);
         }
     } else if (sub == 0) {
         atomicMin(&nxt[s], (uint32_t)i);
