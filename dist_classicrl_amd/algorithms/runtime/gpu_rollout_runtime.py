@@ -34,6 +34,12 @@ def _schedule_values(schedule, n_updates, count):
     return out
 
 
+def _sequential_sum(values: np.ndarray):
+    if len(values) == 0:
+        return 0
+    return np.cumsum(values, dtype=values.dtype)[-1]
+
+
 class GpuRolloutQLearning(BaseRuntime):
     """Drop-in for ``SingleThreadQLearning`` (and, semantically, for the parallel/MPI runtimes)."""
 
@@ -158,7 +164,9 @@ class GpuRolloutQLearning(BaseRuntime):
         reward_history = list(rets)
         states, agent_rewards = env.observe()
         return (
-            sum(reward_history) / len(reward_history),  # ZeroDivisionError if no episode ended (:67)
+            # sum(reward_history) / len(reward_history) of the reference (:67): a sequential float32
+            # accumulation, which is what cumsum computes; ZeroDivisionError if no episode ended
+            _sequential_sum(rets) / len(reward_history),
             reward_history,
             env,
             {"states": states, "infos": [{}] * env.num_agents, "rewards": agent_rewards,

@@ -105,6 +105,7 @@ struct RolloutSlot {
     int n_samples = 0;
     int64_t steps = 0, N = 0, launches = 0;
     int32_t* trace_host = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
     double* dbg = nullptr;  // env->vinc of the rollout in flight (diagnostic builds)
     void release() {
         if (ctrl) (void)hipFree(ctrl);
@@ -114,6 +115,8 @@ struct RolloutSlot {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (sched_ready) (void)hipEventDestroy(sched_ready);
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        graph_exec = nullptr;
         for (hipEvent_t x : sample_ev) (void)hipEventDestroy(x);
         sample_ev.clear();
         ev0 = ev1 = sched_ready = nullptr;
@@ -129,6 +132,7 @@ struct qe_engine {
     uint64_t seed = 0, step_ctr = 0;
     uint32_t agent_offset = 0;
     int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
+    int opt_graph = 1; // QE_OPT_USE_GRAPH
     hipStream_t stream = nullptr;
     bool own_stream = true;
     void* q = nullptr;
@@ -255,6 +259,7 @@ void pack_masks(const uint8_t* masks, int64_t n, int A, std::vector<uint32_t>& o
 
 constexpr int MAX_SAMPLES = 256;
 
+constexpr int GRAPH_STEPS = 50;  // vector steps per captured graph (step-wise / wide paths)
 constexpr int TOKEN_ROUNDS = 4;  // chip-wide rounds before the single-workgroup clean-up (wide mode)
 
 template <typename T, class Env>
@@ -345,11 +350,35 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             HIP_TRY(hipEventCreate(&evn));
             sl.sample_ev.push_back(evn);
         }
-        const int64_t stride = std::max<int64_t>(1, (steps - 1) / MAX_SAMPLES);
-        for (int64_t t = 0; t + 1 < steps; ++t) {
-            const int sample = (t % stride == 0 && sl.n_samples < MAX_SAMPLES) ? sl.n_samples++ : -1;
+        // The steady-state steps all launch the same kernels with the same arguments (the step index
+        // lives in the control block), so a block of GRAPH_STEPS of them is captured once per call
+        // into a HIP graph and replayed: the host no longer pays one launch per kernel.  The first
+        // steps stay eager so that the dominant kernel can be bracketed by events.
+        int64_t done = 0;
+        const int64_t middle = steps - 1;
+        const int64_t eager_head = std::min<int64_t>(middle, 32);
+        for (; done < eager_head; ++done) {
+            const int sample = sl.n_samples < MAX_SAMPLES ? sl.n_samples++ : -1;
             launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, sample);
         }
+        if (e->opt_graph && middle - done >= 2 * GRAPH_STEPS) {
+            if (sl.graph_exec) { (void)hipGraphExecDestroy(sl.graph_exec); sl.graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            const int64_t before = sl.launches;
+            for (int k = 0; k < GRAPH_STEPS; ++k) launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true);
+            const int64_t per_replay = sl.launches - before;
+            sl.launches = before;
+            HIP_TRY(hipStreamEndCapture(e->stream, &graph));
+            const hipError_t ie = hipGraphInstantiate(&sl.graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            HIP_TRY(ie);
+            for (; middle - done >= GRAPH_STEPS; done += GRAPH_STEPS) {
+                HIP_TRY(hipGraphLaunch(sl.graph_exec, e->stream));
+                sl.launches += per_replay;
+            }
+        }
+        for (; done < middle; ++done) launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true);
         launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN, true);  // learn(steps-1)
     } else {
         // greedy evaluation: no table writes, hence no contention and no ordered path
@@ -558,6 +587,7 @@ int qe_synchronize(qe_engine* e) {
 
 int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_ROLLOUT_PATH && value >= 0 && value <= 3) { e->opt_path = (int)value; return QE_OK; }
+    if (option == QE_OPT_USE_GRAPH && (value == 0 || value == 1)) { e->opt_graph = (int)value; return QE_OK; }
     return fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 

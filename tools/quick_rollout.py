@@ -1,5 +1,5 @@
 """Diagnostic: time a rollout for a given shape / epsilon and print device time per step."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
@@ -10,6 +10,9 @@ from dist_classicrl_amd.schedules import ConstantSchedule, ExponentialSchedule
 def run(n, S, A, eps, steps, path="auto", masked=False, mode="iter"):
     algo = OptimalQLearningBase(S, A, 0.99, seed=0)
     algo.set_rollout_path(path)
+    if os.environ.get("QE_NO_GRAPH"):
+        from dist_classicrl_amd import _lib
+        _lib.check(_lib.load().qe_set_option(algo.handle, 1, 0))
     env = HashTabularEnv(n, S, A, seed=1, masked=masked)
     e = ConstantSchedule(eps) if eps is not None else ExponentialSchedule(1.0, 0.01, 0.995)
     rt = GpuRolloutQLearning(algo, ConstantSchedule(0.1), e, learn_mode=mode)
