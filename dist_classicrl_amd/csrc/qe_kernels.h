@@ -417,7 +417,7 @@ __device__ int build_involved_list(const Ctx<T>& c, int* scan) {
 }
 
 template <typename T, class Env, int CAP, int CACHE_BYTES>
-__device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long long t, int M,
+__device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long long t, const int M_all,
                           SlowLdsT<CAP, CACHE_BYTES>& lds) {
     constexpr int HASH = 4 * CAP;
 #ifdef QE_STAMPS
@@ -429,6 +429,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
     const int tid = threadIdx.x, BS = (int)blockDim.x;
     const int L = c.L;
     const int grp = tid >> c.lshift, sub = tid & (L - 1), ngrp = BS >> c.lshift;
+    const int M = M_all;
 
     SB_STAMP(0);
 
@@ -477,8 +478,14 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                 atomicAdd(c.q + (int64_t)c.s[i] * c.ld + c.a[i], (T)inc[i]);
             }
         }
-    } else if (M <= CAP) {
+    } else for (int base = 0; base < M_all; base += CAP) {
         // ---- ITER: dataflow rounds; per shared row, touchers run in agent order ---------------
+        // More involved agents than the LDS structures hold are taken in batches of CAP in agent
+        // order: every dependency points from a lower to a higher agent index, so a batch only
+        // needs the batches before it to be complete (their cells are in the table by then).
+        const int M = min(CAP, M_all - base);
+        const int32_t* list = c.inv_list + base;
+        if (base) __syncthreads();
         for (int k = tid; k < HASH; k += BS) { lds.h_key[k] = -1; lds.h_head[k] = -1; lds.h_done[k] = 0; }
         if (tid == 0) { lds.remaining = M; lds.n_rows = 0; lds.cache_ok = 1; }
         const int row_cap = min((int)lds.kRowCap, (int)(CACHE_BYTES / (c.ld * (int)sizeof(T))));
@@ -486,7 +493,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
         __syncthreads();
         for (int id = tid; id < 2 * M; id += BS) {
             const int pos = id >> 1;
-            const int64_t i = c.inv_list[pos];
+            const int64_t i = list[pos];
             const LiveAgent<T> g = live_agent(c, i);
             const bool need = (id & 1) == 0 || !g.term;  // id even: W(row s); odd: R(row n), unless terminated
             int slot = -1;
@@ -676,7 +683,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                         ordered_learn_cached<T, Env>(c, ev, lds, pos, sub, t, hyper, cache, is,
                                                      sn >= 0 ? (int)lds.h_row[sn] : is);
                     } else {
-                        ordered_learn<T, Env>(c, ev, c.inv_list[pos], sub, t);
+                        ordered_learn<T, Env>(c, ev, list[pos], sub, t);
                     }
                     if (sub == 0) lds.a_state[pos] = 2;
                 }
@@ -697,14 +704,6 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
         if (tid == 0) { c.vinc[14] += (double)rounds; c.vinc[15] += 1.0; }
 #endif
         if (tid == 0 && lds.remaining > 0) c.ctrl->error = 1u;
-    } else {
-        // ---- ITER, too many involved agents for LDS: strictly sequential on one wave ----------
-        if (tid < 64) {
-            for (int pos = 0; pos < M; ++pos) {
-                if (tid < L) ordered_learn<T, Env>(c, ev, c.inv_list[pos], tid, t);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            }
-        }
     }
     __syncthreads();
 

@@ -170,7 +170,10 @@ def test_rollout_matches_reference_golden(name, path):
     [
         (("hash", 1024, 5000, 16, False), 30, "f4", "iter"),
         (("hash", 1024, 5000, 16, False), 30, "f8", "iter"),
-        (("hash", 4096, 300, 8, False), 12, "f4", "iter"),  # > 1024 involved agents: sequential path
+        (("hash", 4096, 300, 8, False), 12, "f4", "iter"),  # > 1024 involved agents: batched ordered path
+        (("hash", 8192, 150, 4, False), 8, "f4", "iter"),  # eight batches, long same-cell chains
+        (("hash", 3000, 40000, 16, False), 10, "f8", "iter"),  # batches whose rows overflow the LDS row cache
+        (("hash", 5000, 600, 40, True), 6, "f4", "iter"),
         (("hash", 512, 2000, 64, True), 20, "f4", "iter"),
         (("hash", 300, 100000, 32, False), 25, "f4", "iter"),
         (("hash", 700, 1000, 4, False), 25, "f8", "iter"),
