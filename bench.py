@@ -137,6 +137,10 @@ def main() -> None:
                              agent_offset=rank * n)
     rt = GpuRolloutQLearning(algo, ExponentialSchedule(0.1, 1e-5, 0.995),
                              ExponentialSchedule(1.0, 0.01, 0.995), learn_mode=args.mode)
+    if n >= 16384:
+        # hundreds of thousands of episodes end per call: take the returns as one float32 array
+        # instead of a Python list with one object per episode (the values are the same)
+        rt.history_type = "array"
     if use_dist:
         from dist_classicrl_amd.distributed.delta_sync import attach_engine
 
@@ -199,7 +203,8 @@ def main() -> None:
             "workload": f"{args.workload}: {n} agents/GPU, {wl['states']} states x {wl['actions']} actions, "
                         f"fp32 Q-table, {'TicTacToeEnv' if wl.get('env') == 'tictactoe' else 'HashTabularEnv'}"
                         f"{' (masked)' if wl['masked'] else ''}, "
-                        f"learn={args.mode}, benchmark-default schedules",
+                        f"learn={args.mode}, benchmark-default schedules"
+                        f"{', episode returns as array' if rt.history_type == 'array' else ''}",
             "agents_per_gpu": n, "states": wl["states"], "actions": wl["actions"],
             "sync_every": SYNC_EVERY if use_dist else None,
             "parallelism": f"agents sharded x{n_gpus}, table replicas + RCCL delta all-gather" if n_gpus > 1 else "1 GPU",

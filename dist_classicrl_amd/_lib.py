@@ -21,6 +21,9 @@ QE_F32, QE_F64 = 0, 1
 LEARN_ITER, LEARN_VEC = 0, 1
 ENV_HASH, ENV_GRID, ENV_BANDIT, ENV_TICTACTOE = 0, 1, 2, 3
 OPT_ROLLOUT_PATH = 0
+OPT_USE_GRAPH = 1
+OPT_TOKEN_ROUNDS = 2
+OPT_LISTED_MIN_AGENTS = 3
 PATH_AUTO, PATH_STEPWISE, PATH_PERSISTENT, PATH_WIDE = 0, 1, 2, 3
 
 ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INDEX = -1, -2, -3, -4, -5

@@ -100,6 +100,10 @@ class OptimalQLearningBase:
                 "wide": _lib.PATH_WIDE}[path]
         _lib.check(self._lib.qe_set_option(self._h, _lib.OPT_ROLLOUT_PATH, code))
 
+    def set_engine_option(self, option: int, value: int) -> None:
+        """Other tuning knobs of ``include/qlearn_engine.h`` (``_lib.OPT_*``); none changes results."""
+        _lib.check(self._lib.qe_set_option(self._h, int(option), int(value)))
+
     @property
     def lanes_per_row(self) -> int:
         """Lanes of a wavefront that share one Q-table row (power of two, 4 columns per lane)."""

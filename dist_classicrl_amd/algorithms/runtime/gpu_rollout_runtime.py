@@ -53,6 +53,16 @@ class GpuRolloutQLearning(BaseRuntime):
         self.delta_sync = None  # dist_classicrl_amd.distributed.DeltaSync (multi-GPU replicas)
         self.sync_every = 100
         self.trace_actions = None  # set to True to collect every action (tests)
+        # element type of the reward history `run_steps` returns: "float" (list of Python floats, the
+        # float32 returns widened exactly), "float32" (list of numpy.float32 scalars, the reference's
+        # element type, ~2x slower to build) or "array" (the float32 array itself: no per-episode
+        # Python object; for runs that finish millions of episodes per call)
+        self.history_type = "float"
+
+    def _history(self, rets: np.ndarray):
+        if self.history_type == "array":
+            return rets
+        return list(rets) if self.history_type == "float32" else rets.tolist()
 
     def init_training(self) -> None:
         return None
@@ -161,7 +171,7 @@ class GpuRolloutQLearning(BaseRuntime):
         else:
             env.restore(curr_state_dict["states"], curr_state_dict["rewards"])
         rets, _ = self._rollout(env, steps, learn=True)
-        reward_history = list(rets)
+        reward_history = self._history(rets)
         states, agent_rewards = env.observe()
         return (
             # sum(reward_history) / len(reward_history) of the reference (:67): a sequential float32

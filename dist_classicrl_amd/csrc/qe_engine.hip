@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -80,6 +81,36 @@ struct PinnedBuf {  // page-locked host staging: async copies without a host-sid
     }
 };
 
+// Episode-log entries by key = (step << 32 | agent): the append order of base_runtime.py:218-221.
+// Keys are unique; large logs (tens of thousands of episodes per chunk at many agents) take an LSD
+// radix sort over the significant key bits instead of a comparison sort.
+void sort_episode_log(std::vector<std::pair<unsigned long long, float>>& v,
+                      std::vector<std::pair<unsigned long long, float>>& tmp) {
+    if (v.size() < 4096) {
+        std::sort(v.begin(), v.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        return;
+    }
+    // only bits that differ between keys need sorting
+    unsigned long long all_or = 0, all_and = ~0ull;
+    for (const auto& x : v) { all_or |= x.first; all_and &= x.first; }
+    const unsigned long long varying = all_or & ~all_and;
+    tmp.resize(v.size());
+    constexpr int DIGIT = 11;
+    std::vector<size_t> count((size_t)1 << DIGIT);
+    auto* src = &v;
+    auto* dst = &tmp;
+    for (int shift = 0; shift < 64; shift += DIGIT) {
+        if (((varying >> shift) & ((1ull << DIGIT) - 1)) == 0) continue;
+        std::fill(count.begin(), count.end(), 0);
+        for (const auto& x : *src) ++count[(x.first >> shift) & ((1u << DIGIT) - 1)];
+        size_t run = 0;
+        for (auto& cnt : count) { const size_t c0 = cnt; cnt = run; run += c0; }
+        for (const auto& x : *src) (*dst)[count[(x.first >> shift) & ((1u << DIGIT) - 1)]++] = x;
+        std::swap(src, dst);
+    }
+    if (src != &v) v.swap(tmp);
+}
+
 int lanes_per_row(int ld) {  // smallest power of two L with 4*L >= ld
     int L = 1;
     while (4 * L < ld) L <<= 1;
@@ -88,29 +119,37 @@ int lanes_per_row(int ld) {  // smallest power of two L with 4*L >= ld
 
 }  // namespace
 
+constexpr int MAX_TOKEN_ROUNDS = 24;   // chip-wide rounds before the single-workgroup clean-up (wide mode)
+constexpr int64_t LISTED_MIN_AGENTS = 16384;  // from here on the rounds walk compacted lists
+constexpr int LISTED_MIN_ROUNDS = 6;   // ... and only when at least this many rounds run
+constexpr int LISTED_RECOMPACT = 3;    // rounds on the first list before the second compaction
+constexpr unsigned LISTED_GRID = 1024; // blocks of a listed round (grid-stride)
+
 // Everything one in-flight rollout owns, so that the next rollout can be enqueued before the results
 // of the previous one are read back.
 struct RolloutSlot {
     Ctrl* ctrl = nullptr;
-    DevBuf<unsigned long long> thr, ep_key;
+    DevBuf<unsigned long long> thr, ep_key, ep_key_packed;
     DevBuf<double> lr;
-    DevBuf<float> ep_ret;
+    DevBuf<float> ep_ret, ep_ret_packed;
     PinnedBuf<unsigned long long> h_thr, h_key;
     PinnedBuf<double> h_lr;
     PinnedBuf<float> h_ret;
     PinnedBuf<Ctrl> h_ctrl;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, sched_ready = nullptr;
     std::vector<hipEvent_t> sample_ev;  // event pairs around sampled dominant-kernel launches
-    bool busy = false, persistent = false;
+    bool busy = false, persistent = false, wide = false;
     int n_samples = 0;
     int64_t steps = 0, N = 0, launches = 0;
     int32_t* trace_host = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    int rounds = 4;  // token rounds per step of this call (wide mode)
     double* dbg = nullptr;  // env->vinc of the rollout in flight (diagnostic builds)
     void release() {
         if (ctrl) (void)hipFree(ctrl);
         ctrl = nullptr;
         thr.release(); ep_key.release(); lr.release(); ep_ret.release();
+        ep_key_packed.release(); ep_ret_packed.release();
         h_thr.release(); h_key.release(); h_lr.release(); h_ret.release(); h_ctrl.release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -133,6 +172,9 @@ struct qe_engine {
     uint32_t agent_offset = 0;
     int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
     int opt_graph = 1; // QE_OPT_USE_GRAPH
+    int opt_rounds = 0; // QE_OPT_TOKEN_ROUNDS (0 = automatic)
+    int auto_rounds = 4; // wide mode: rounds chosen from the previous call's statistics
+    int64_t listed_min = LISTED_MIN_AGENTS;  // QE_OPT_LISTED_MIN_AGENTS
     hipStream_t stream = nullptr;
     bool own_stream = true;
     void* q = nullptr;
@@ -153,7 +195,7 @@ struct qe_engine {
     DevBuf<unsigned long long> ep_key;
     DevBuf<float> ep_ret;
     long long ep_cap = 1 << 22;
-    std::vector<std::pair<unsigned long long, float>> ep_host;
+    std::vector<std::pair<unsigned long long, float>> ep_host, ep_tmp;
     // delta log (caller-owned buffer)
     DeltaEntry* dlog = nullptr;
     long long dlog_cap = 0, dlog_count = 0;
@@ -167,7 +209,7 @@ struct qe_env {
     qe_engine* e = nullptr;
     qe_env_params p{};
     int64_t N = 0;
-    DevBuf<int32_t> s, a, n, list;
+    DevBuf<int32_t> s, a, n, list, pend_list;
     DevBuf<float> r, acc;
     DevBuf<uint8_t> term, pred, masks;
     DevBuf<uint32_t> aux, bitmap, adv_bitmap;
@@ -260,7 +302,6 @@ void pack_masks(const uint8_t* masks, int64_t n, int A, std::vector<uint32_t>& o
 constexpr int MAX_SAMPLES = 256;
 
 constexpr int GRAPH_STEPS = 50;  // vector steps per captured graph (step-wise / wide paths)
-constexpr int TOKEN_ROUNDS = 4;  // chip-wide rounds before the single-workgroup clean-up (wide mode)
 
 template <typename T, class Env>
 void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow,
@@ -272,11 +313,32 @@ void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& e
     ++sl.launches;
     if (!slow) return;
     if (c.tok) {  // wide mode: token rounds on the whole chip, clean-up, postponed selections
-        for (int r = 0; r < TOKEN_ROUNDS; ++r)
+        const int rounds = sl.rounds;
+        if (c.pend_list) {
+            const dim3 cgrid(grid_for((c.N + 31) / 32, FAST_BLOCK));
+            const dim3 lgrid(std::min<unsigned>(grid.x, LISTED_GRID));
+            hipLaunchKernelGGL((k_compact<T>), cgrid, block, 0, e->stream, c, (const uint32_t*)c.inv_bitmap, c.pend_list, 0);
+            int launches = 3;
+            for (int r = 0; r < rounds; ++r) {
+                if (r == LISTED_RECOMPACT) {
+                    hipLaunchKernelGGL((k_compact<T>), cgrid, block, 0, e->stream, c, (const uint32_t*)c.inv_bitmap, c.inv_list, 1);
+                    ++launches;
+                }
+                const bool second = r >= LISTED_RECOMPACT;
+                hipLaunchKernelGGL((k_token_round_list<T, Env>), lgrid, block, 0, e->stream, c, ev, flags, r,
+                                   (const int32_t*)(second ? c.inv_list : c.pend_list), second ? 1 : 0);
+            }
+            hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
+            hipLaunchKernelGGL((k_advance_list<T, Env>), lgrid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1,
+                               (const int32_t*)c.pend_list);
+            sl.launches += rounds + launches;
+            return;
+        }
+        for (int r = 0; r < rounds; ++r)
             hipLaunchKernelGGL((k_token_round<T, Env>), grid, block, 0, e->stream, c, ev, flags, r);
         hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
         hipLaunchKernelGGL((k_advance<T, Env>), grid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1);
-        sl.launches += TOKEN_ROUNDS + 2;
+        sl.launches += rounds + 2;
         return;
     }
     hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
@@ -315,8 +377,12 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         }
         c.tok = e->tok;
         c.adv_bitmap = env->adv_bitmap.p;
+        sl.rounds = e->opt_rounds ? e->opt_rounds : e->auto_rounds;
+        // compacted lists pay for their two extra launches only when many rounds walk them
+        if (env->N >= e->listed_min && sl.rounds >= LISTED_MIN_ROUNDS) c.pend_list = env->pend_list.p;
     }
     sl.launches = 0; sl.n_samples = 0; sl.steps = steps; sl.N = env->N; sl.persistent = persistent;
+    sl.wide = wide;
     sl.trace_host = trace_host;
     sl.dbg = env->vinc.p;
     if (!persistent) HIP_TRY(hipMemsetAsync(sl.ctrl, 0, sizeof(Ctrl), e->stream));  // persistent kernel: in-kernel
@@ -386,6 +452,14 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                            e->stream, c, ev, (long long)steps);
         ++sl.launches;
     }
+    if (!persistent) {
+        HIP_TRY(sl.ep_key_packed.ensure((size_t)e->ep_cap));
+        HIP_TRY(sl.ep_ret_packed.ensure((size_t)e->ep_cap));
+        hipLaunchKernelGGL(k_log_gather, dim3(64), dim3(256), 0, e->stream, (const Ctrl*)sl.ctrl,
+                           (const unsigned long long*)sl.ep_key.p, (const float*)sl.ep_ret.p, (long long)e->ep_cap,
+                           sl.ep_key_packed.p, sl.ep_ret_packed.p);
+        ++sl.launches;
+    }
     HIP_TRY(hipEventRecord(sl.ev1, e->stream));
     HIP_TRY(hipGetLastError());
     if (c.dlog) e->dlog_count = std::min<long long>(e->dlog_count + steps * env->N, e->dlog_cap);
@@ -406,6 +480,13 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
     const Ctrl fin = *sl.h_ctrl.p;
+    if (sl.wide && sl.steps > 0) {
+        // Number of chip-wide token rounds of the NEXT calls: every round roughly halves the agents that
+        // are left for the single-workgroup ordered path; aim at a few hundred of those per step.
+        const double left = (double)fin.involved_total / (double)sl.steps;
+        if (left > 400.0) e->auto_rounds = std::min(MAX_TOKEN_ROUNDS, e->auto_rounds + 2);
+        else if (left < 100.0 && e->auto_rounds > 2) e->auto_rounds -= 1;
+    }
     // episode log -> host, sorted by (step, agent) = append order of base_runtime.py:218-221.
     // The persistent kernel writes a linear log (ep_count entries); the step-wise kernels write 64
     // segments of ep_cap/64 entries each (ep_seg[] counts).
@@ -429,20 +510,14 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         if (sl.persistent) {
             HIP_TRY(hipMemcpyAsync(sl.h_key.p, sl.ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
             HIP_TRY(hipMemcpyAsync(sl.h_ret.p, sl.ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost, e->copy_stream));
-        } else {
-            long long off = 0;
-            for (int k = 0; k < 64; ++k) {
-                if (!seg_got[k]) continue;
-                HIP_TRY(hipMemcpyAsync(sl.h_key.p + off, sl.ep_key.p + k * seg_cap, seg_got[k] * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
-                HIP_TRY(hipMemcpyAsync(sl.h_ret.p + off, sl.ep_ret.p + k * seg_cap, seg_got[k] * sizeof(float), hipMemcpyDeviceToHost, e->copy_stream));
-                off += seg_got[k];
-            }
+        } else {  // packed by k_log_gather at the end of the rollout
+            HIP_TRY(hipMemcpyAsync(sl.h_key.p, sl.ep_key_packed.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
+            HIP_TRY(hipMemcpyAsync(sl.h_ret.p, sl.ep_ret_packed.p, got * sizeof(float), hipMemcpyDeviceToHost, e->copy_stream));
         }
         HIP_TRY(hipStreamSynchronize(e->copy_stream));
         for (long long k = 0; k < got; ++k) e->ep_host[(size_t)k] = {sl.h_key.p[k], sl.h_ret.p[k]};
     }
-    std::sort(e->ep_host.begin(), e->ep_host.end(),
-              [](const auto& x, const auto& y) { return x.first < y.first; });
+    sort_episode_log(e->ep_host, e->ep_tmp);
     if (sl.trace_host) {
         HIP_TRY(hipMemcpyAsync(sl.trace_host, e->trace.p, sl.steps * sl.N * sizeof(int32_t), hipMemcpyDeviceToHost, e->copy_stream));
         HIP_TRY(hipStreamSynchronize(e->copy_stream));
@@ -537,6 +612,9 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     if (e->L > 64) e->L = 64;  // A > 256: the wave-per-row kernels take over
     for (e->lshift = 0; (1 << e->lshift) < e->L; ++e->lshift) {}
     e->gamma = gamma; e->seed = seed;
+    // tuning overrides for experiments (same meaning as the qe_set_option knobs; results never change)
+    if (const char* v = getenv("QE_TOKEN_ROUNDS")) e->opt_rounds = std::max(0, std::min(MAX_TOKEN_ROUNDS, atoi(v)));
+    if (const char* v = getenv("QE_LISTED_MIN_AGENTS")) e->listed_min = std::max(1, atoi(v));
     const size_t bytes = (size_t)S * e->ld * e->esize();
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
@@ -588,6 +666,8 @@ int qe_synchronize(qe_engine* e) {
 int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_ROLLOUT_PATH && value >= 0 && value <= 3) { e->opt_path = (int)value; return QE_OK; }
     if (option == QE_OPT_USE_GRAPH && (value == 0 || value == 1)) { e->opt_graph = (int)value; return QE_OK; }
+    if (option == QE_OPT_LISTED_MIN_AGENTS && value >= 1) { e->listed_min = value; return QE_OK; }
+    if (option == QE_OPT_TOKEN_ROUNDS && value >= 0 && value <= MAX_TOKEN_ROUNDS) { e->opt_rounds = (int)value; return QE_OK; }
     return fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 
@@ -804,6 +884,7 @@ int qe_env_create(qe_env** out, qe_engine* e, int64_t N, const qe_env_params* p)
     if (err == hipSuccess) err = env->a.ensure(un);
     if (err == hipSuccess) err = env->n.ensure(un);
     if (err == hipSuccess) err = env->list.ensure(un);
+    if (err == hipSuccess) err = env->pend_list.ensure(un);
     if (err == hipSuccess) err = env->r.ensure(un);
     if (err == hipSuccess) err = env->acc.ensure(un);
     if (err == hipSuccess) err = env->term.ensure(un);
@@ -826,7 +907,7 @@ int qe_env_destroy(qe_env* env) {
     if (!env) return QE_OK;
     (void)hipSetDevice(env->e->device);
     (void)hipStreamSynchronize(env->e->stream);
-    env->s.release(); env->a.release(); env->n.release(); env->list.release(); env->r.release();
+    env->s.release(); env->a.release(); env->n.release(); env->list.release(); env->pend_list.release(); env->r.release();
     env->acc.release(); env->term.release(); env->pred.release(); env->aux.release();
     env->bitmap.release(); env->adv_bitmap.release(); env->masks.release(); env->vinc.release();
     delete env;

@@ -45,7 +45,9 @@ struct Ctrl {
     unsigned int error;                  // set by a kernel that had to give up (never expected)
     unsigned long long ep_count;         // episode-log entries written (persistent kernel: linear log)
     unsigned int ep_seg[64];             // entries per log segment (step-wise kernels: segmented log)
-    unsigned long long involved_total;   // statistics
+    unsigned long long involved_total;   // statistics: agents that reached the ordered path
+    unsigned long long pending_total;    // statistics (wide mode, listed rounds): agents that entered the token rounds
+    unsigned int pend_count[2];          // entries of the two pending lists of the current step
 };
 
 struct DeltaEntry {
@@ -65,6 +67,7 @@ struct Ctx {
     double* vinc;           // N: VEC-mode increments of involved agents
     uint32_t* tok;          // [2][S] lowest pending agent per row (wide mode; nullptr otherwise)
     uint32_t* adv_bitmap;   // agents whose selection of step t+1 waits for all updates of step t
+    int32_t* pend_list;     // N: agents that entered the token rounds of this step (wide mode at large N)
     Ctrl* ctrl;
     // agent state: pending transition (s, a, pred, r, term) and current observation n
     int32_t* s;
@@ -123,6 +126,21 @@ __device__ __forceinline__ void log_episode(const Ctx<T>& c, long long t, int64_
         const long long at = (long long)seg * seg_cap + p;
         c.ep_key[at] = ((unsigned long long)t << 32) | (unsigned long long)i;
         c.ep_ret[at] = ret;
+    }
+}
+
+// The 64 segments of the step-wise episode log, packed back to back (one workgroup per segment), so
+// that the host fetches the log of a rollout with two copies.
+__global__ __launch_bounds__(256) void k_log_gather(const Ctrl* ctrl, const unsigned long long* key, const float* ret,
+                                                    long long ep_cap, unsigned long long* key_out, float* ret_out) {
+    const long long seg_cap = ep_cap >> 6;
+    const int seg = (int)blockIdx.x;
+    long long off = 0;
+    for (int k = 0; k < seg; ++k) off += min((long long)ctrl->ep_seg[k], seg_cap);
+    const long long cnt = min((long long)ctrl->ep_seg[seg], seg_cap);
+    for (long long j = threadIdx.x; j < cnt; j += blockDim.x) {
+        key_out[off + j] = key[seg * seg_cap + j];
+        ret_out[off + j] = ret[seg * seg_cap + j];
     }
 }
 
@@ -211,6 +229,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
     const int sub = (int)(gl & (c.L - 1));
     if (i >= c.N) return;  // whole lane groups leave together (L divides the block size)
     const long long t = c.ctrl->t_local;
+    if (gl == 0) { c.ctrl->pend_count[0] = 0u; c.ctrl->pend_count[1] = 0u; }  // lists of the previous step
     const int32_t n = c.n[i];
     Row4<T> row = load_row4(c.q, n, c.ld, sub);  // speculative: discarded if the row is contested
     const uint32_t valid = Env::valid4(ev, i, n, sub);
@@ -1090,13 +1109,8 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
 // row.  After a fixed number of rounds the single-workgroup slow_body finishes whatever is left
 // (long chains), and k_advance performs the postponed selections once every update of the step is in.
 template <typename T, class Env>
-__global__ __launch_bounds__(FAST_BLOCK) void k_token_round(Ctx<T> c, EnvCtx ev, int flags, int round) {
-    const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
-    const int64_t i = gl >> c.lshift;
-    const int sub = (int)(gl & (c.L - 1));
-    if (i >= c.N) return;
-    if (!((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u)) return;  // not pending (whole lane group leaves)
-    const long long t = c.ctrl->t_local;
+__device__ __forceinline__ void token_round_agent(const Ctx<T>& c, const EnvCtx& ev, int flags, int round,
+                                                  int64_t i, int sub, long long t) {
     const int32_t s = c.s[i], a = c.a[i], n = c.n[i];
     const bool term = c.term[i] != 0;
     const bool need_n = !term && n != s;
@@ -1129,16 +1143,63 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_token_round(Ctx<T> c, EnvCtx ev,
     }
 }
 
-// Postponed selections of wide mode: every agent that was involved in step t selects its action of
-// step t+1 only now, when all updates of step t are in the table (also clears its stamps).
 template <typename T, class Env>
-__global__ __launch_bounds__(FAST_BLOCK) void k_advance(Ctx<T> c, EnvCtx ev, int flags) {
+__global__ __launch_bounds__(FAST_BLOCK) void k_token_round(Ctx<T> c, EnvCtx ev, int flags, int round) {
     const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
     const int64_t i = gl >> c.lshift;
     const int sub = (int)(gl & (c.L - 1));
     if (i >= c.N) return;
-    if (!((c.adv_bitmap[i >> 5] >> (i & 31)) & 1u)) return;
-    const long long t = c.ctrl->t_local - ((flags & FLAG_T_MINUS_1) ? 1 : 0);
+    if (!((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u)) return;  // not pending (whole lane group leaves)
+    token_round_agent<T, Env>(c, ev, flags, round, i, sub, c.ctrl->t_local);
+}
+
+// At large N a round that scans every agent costs more than the work of the few that are still
+// pending.  k_compact turns a bitmap (all involved agents after k_step_fast; the still-pending ones
+// a few rounds later) into a list, and the listed variants of the round / of the postponed selection
+// walk that list with a fixed, modest grid (grid-stride).  Stale entries of a list (agents that have
+// finished since it was built) are skipped by their bitmap bit.
+template <typename T>
+__global__ __launch_bounds__(FAST_BLOCK) void k_compact(Ctx<T> c, const uint32_t* bitmap, int32_t* list, int which) {
+    __shared__ int scan[18];
+    __shared__ unsigned base_s;
+    const int W = (int)((c.N + 31) >> 5);
+    const int w = (int)blockIdx.x * FAST_BLOCK + (int)threadIdx.x;
+    uint32_t word = w < W ? bitmap[w] : 0u;
+    int total;
+    int p = block_excl_scan(__popc(word), &total, scan);
+    if (total == 0) return;  // uniform over the block
+    if (threadIdx.x == 0) {
+        base_s = atomicAdd(&c.ctrl->pend_count[which], (unsigned)total);
+        if (which == 0) atomicAdd(&c.ctrl->pending_total, (unsigned long long)total);
+    }
+    __syncthreads();
+    p += (int)base_s;
+    while (word) {
+        const int b = __ffs(word) - 1;
+        list[p++] = w * 32 + b;
+        word &= word - 1u;
+    }
+}
+
+template <typename T, class Env>
+__global__ __launch_bounds__(FAST_BLOCK) void k_token_round_list(Ctx<T> c, EnvCtx ev, int flags, int round,
+                                                                 const int32_t* list, int which) {
+    const int count = (int)c.ctrl->pend_count[which];
+    const int gpb = FAST_BLOCK >> c.lshift;  // lane groups per block
+    const int sub = (int)(threadIdx.x & (c.L - 1));
+    const long long t = c.ctrl->t_local;
+    for (int p = (int)blockIdx.x * gpb + (int)(threadIdx.x >> c.lshift); p < count; p += (int)gridDim.x * gpb) {
+        const int64_t i = list[p];
+        if (!((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u)) continue;
+        token_round_agent<T, Env>(c, ev, flags, round, i, sub, t);
+    }
+}
+
+// Postponed selections of wide mode: every agent that was involved in step t selects its action of
+// step t+1 only now, when all updates of step t are in the table (also clears its stamps).
+template <typename T, class Env>
+__device__ __forceinline__ void advance_postponed(const Ctx<T>& c, const EnvCtx& ev, int flags, int64_t i, int sub,
+                                                  long long t) {
     const int32_t s = c.s[i], n = c.n[i];
     if (sub == 0) {
         const int par = (int)(t & 1);
@@ -1150,6 +1211,28 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_advance(Ctx<T> c, EnvCtx ev, int
         Row4<T> row = load_row4(c.q, n, c.ld, sub);
         advance_agent<T, Env>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
     }
+}
+
+template <typename T, class Env>
+__global__ __launch_bounds__(FAST_BLOCK) void k_advance(Ctx<T> c, EnvCtx ev, int flags) {
+    const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
+    const int64_t i = gl >> c.lshift;
+    const int sub = (int)(gl & (c.L - 1));
+    if (i >= c.N) return;
+    if (!((c.adv_bitmap[i >> 5] >> (i & 31)) & 1u)) return;
+    advance_postponed<T, Env>(c, ev, flags, i, sub, c.ctrl->t_local - ((flags & FLAG_T_MINUS_1) ? 1 : 0));
+}
+
+// Listed variant: the first pending list of the step holds exactly the agents whose selection was
+// postponed.  The last block to leave resets the list counters for the next step.
+template <typename T, class Env>
+__global__ __launch_bounds__(FAST_BLOCK) void k_advance_list(Ctx<T> c, EnvCtx ev, int flags, const int32_t* list) {
+    const int count = (int)c.ctrl->pend_count[0];
+    const int gpb = FAST_BLOCK >> c.lshift;
+    const int sub = (int)(threadIdx.x & (c.L - 1));
+    const long long t = c.ctrl->t_local - ((flags & FLAG_T_MINUS_1) ? 1 : 0);
+    for (int p = (int)blockIdx.x * gpb + (int)(threadIdx.x >> c.lshift); p < count; p += (int)gridDim.x * gpb)
+        advance_postponed<T, Env>(c, ev, flags, list[p], sub, t);
 }
 
 // -------------------------------------------------------------------------------------------------

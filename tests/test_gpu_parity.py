@@ -117,7 +117,7 @@ def test_learn_vec_many_collisions_atomic_path():
 
 
 # ------------------------------------------------------------------------------- closed loop
-PATHS = ["stepwise", "persistent", "wide"]
+PATHS = ["stepwise", "persistent", "wide", "wide_listed"]
 
 
 def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="auto"):
@@ -126,9 +126,15 @@ def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="a
     algo = Algo(env.state_size, env.action_size, gamma, seed=seed, dtype=np.dtype(dt))
     if path == "persistent" and (env.num_agents * algo.lanes_per_row > 1024 or env.num_agents > 512):
         pytest.skip("more than 512 agents / 1024 lanes: the persistent kernel does not apply")
-    if path == "wide" and mode == "vec":
+    if path.startswith("wide") and mode == "vec":
         pytest.skip("the token rounds implement the sequential semantics only")
-    algo.set_rollout_path(path)
+    if path == "wide_listed":  # the compacted-list rounds (automatic from 16384 agents), seven rounds
+        from dist_classicrl_amd import _lib
+        algo.set_rollout_path("wide")
+        algo.set_engine_option(_lib.OPT_LISTED_MIN_AGENTS, 1)
+        algo.set_engine_option(_lib.OPT_TOKEN_ROUNDS, 7)  # >= 6: lists are used
+    else:
+        algo.set_rollout_path(path)
     lr_p, eps_p = schedule_params(sched)
     rt = Runtime(algo, make_schedule(lr_p), make_schedule(eps_p), learn_mode=mode)
     rt.trace_actions = True

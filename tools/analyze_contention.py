@@ -68,3 +68,33 @@ for rep in range(3):
     print(f"step {run.step}: involved {len(idx)} of {n}; rows {len({int(s[i]) for i in idx} | {int(nxt[i]) for i in idx})}; "
           f"components {len(sizes)} (largest {sizes[:5].tolist()}); longest chain {dmax}; "
           f"distinct cells {len(cs)} (largest {cs[:5].tolist()}); agents in cells with >1 writer {int(cs[cs > 1].sum())}")
+    # ---- how many agents are still pending after r rounds under three scheduling rules
+    si, ni, ti = s[idx].astype(np.int64), nxt[idx].astype(np.int64), term[idx]
+    INF = np.iinfo(np.int64).max
+    def simulate(rule, rounds=40):
+        pend = np.ones(len(idx), dtype=bool)
+        left = []
+        for _ in range(rounds):
+            p = np.flatnonzero(pend)
+            if len(p) == 0:
+                break
+            wmin, rmin = defaultdict(lambda: INF), defaultdict(lambda: INF)
+            for k in p:
+                i = int(idx[k])
+                wmin[si[k]] = min(wmin[si[k]], i)
+                if not ti[k]:
+                    rmin[ni[k]] = min(rmin[ni[k]], i)
+            for k in p:
+                i = int(idx[k])
+                if rule == "one":   # one token per row: lowest pending toucher of every row
+                    ok = min(wmin[si[k]], rmin[si[k]]) == i and (ti[k] or min(wmin[ni[k]], rmin[ni[k]]) == i)
+                else:               # reader / writer tokens
+                    ok = wmin[si[k]] == i and rmin[si[k]] >= i and (ti[k] or wmin[ni[k]] >= i)
+                if ok:
+                    pend[k] = False
+            left.append(int(pend.sum()))
+        return left
+    print("  one token per row :", simulate("one")[:32])
+    print("  reader/writer toks:", simulate("rw")[:32])
+    hist = np.bincount(np.array(list(depth.values())))
+    print("  true-dependency depth: agents left after round r:", (len(idx) - np.cumsum(hist)[1:]).tolist()[:32])

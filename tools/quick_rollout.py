@@ -10,9 +10,13 @@ from dist_classicrl_amd.schedules import ConstantSchedule, ExponentialSchedule
 def run(n, S, A, eps, steps, path="auto", masked=False, mode="iter"):
     algo = OptimalQLearningBase(S, A, 0.99, seed=0)
     algo.set_rollout_path(path)
+    from dist_classicrl_amd import _lib
     if os.environ.get("QE_NO_GRAPH"):
-        from dist_classicrl_amd import _lib
         _lib.check(_lib.load().qe_set_option(algo.handle, 1, 0))
+    if os.environ.get("QE_LISTED_MIN"):
+        _lib.check(_lib.load().qe_set_option(algo.handle, 3, int(os.environ["QE_LISTED_MIN"])))
+    if os.environ.get("QE_ROUNDS"):
+        _lib.check(_lib.load().qe_set_option(algo.handle, 2, int(os.environ["QE_ROUNDS"])))
     env = HashTabularEnv(n, S, A, seed=1, masked=masked)
     e = ConstantSchedule(eps) if eps is not None else ExponentialSchedule(1.0, 0.01, 0.995)
     rt = GpuRolloutQLearning(algo, ConstantSchedule(0.1), e, learn_mode=mode)
