@@ -109,28 +109,80 @@ __device__ __forceinline__ Row4<T> load_row4_live(const T* q, int64_t row, int l
     return r;
 }
 
-// Lane-group reductions.  `LC` > 0 fixes the group width at compile time (the shuffles then lower to
-// DPP moves instead of LDS-crossbar ds_bpermute, which matters in the latency-bound persistent
-// kernel); LC == 0 takes the runtime width `L`.
+// ---------------------------------------------------------------------------------------------
+// Lane-group data exchange.  hipcc lowers every __shfl* to ds_bpermute_b32 -- an LDS-crossbar round
+// trip (address arithmetic + ~100 cycles when the result is needed at once), and the selection of one
+// action is a chain of a dozen dependent ones.  When the group width is a compile-time constant of 2
+// or 4 lanes (`LC`; groups are quad-aligned) the same exchanges are single DPP moves (quad_perm /
+// row_shr), issued by the VALU at full rate.  Partners and operation order are those of the generic
+// code, so results are identical bit for bit.  LC == 0 (runtime width `L`) and wider groups keep the
+// generic shuffles.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned v) { return (unsigned)dpp_mov<CTRL>((int)v); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) { return __int_as_float(dpp_mov<CTRL>(__float_as_int(v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    return __hiloint2double(dpp_mov<CTRL>(__double2hiint(v)), dpp_mov<CTRL>(__double2loint(v)));
+}
+constexpr int DPP_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int DPP_SHR1 = 0x111;    // row_shr:1
+constexpr int DPP_SHR2 = 0x112;    // row_shr:2
+constexpr bool dpp_width(int LC) { return LC == 2 || LC == 4; }
+
+// value held by lane K of the group (K a compile-time constant)
+template <int LC, int K, typename T>
+__device__ __forceinline__ T group_bcast(T v, int L) {
+    if constexpr (LC == 4) return dpp_mov<K * 0x55>(v);                 // quad_perm:[K,K,K,K]
+    else if constexpr (LC == 2) return dpp_mov<K ? 0xF5 : 0xA0>(v);     // quad_perm:[K,K,2+K,2+K]
+    else return __shfl(v, K, LC ? LC : L);
+}
+
 template <int LC = 0, typename T>
 __device__ __forceinline__ T group_max(T v, int L) {
-    if (LC) L = LC;
-#pragma unroll
-    for (int off = L >> 1; off > 0; off >>= 1) {
-        const T o = __shfl_xor(v, off, L);
+    if constexpr (LC == 4) {
+        T o = dpp_mov<DPP_XOR2>(v);
         v = o > v ? o : v;
     }
-    return v;
+    if constexpr (dpp_width(LC)) {
+        const T o = dpp_mov<DPP_XOR1>(v);
+        return o > v ? o : v;
+    } else {
+        if (LC) L = LC;
+#pragma unroll
+        for (int off = L >> 1; off > 0; off >>= 1) {
+            const T o = __shfl_xor(v, off, L);
+            v = o > v ? o : v;
+        }
+        return v;
+    }
 }
 template <int LC = 0>
 __device__ __forceinline__ int group_max_int(int v, int L) {
-    if (LC) L = LC;
-#pragma unroll
-    for (int off = L >> 1; off > 0; off >>= 1) {
-        const int o = __shfl_xor(v, off, L);
-        v = o > v ? o : v;
-    }
-    return v;
+    return group_max<LC, int>(v, L);
+}
+// bitwise OR over the group (used to fetch the value of ONE lane chosen at run time: the others
+// contribute zero)
+template <int LC>
+__device__ __forceinline__ unsigned group_or(unsigned v) {
+    static_assert(dpp_width(LC), "DPP widths only");
+    if constexpr (LC == 4) v |= dpp_mov<DPP_XOR2>(v);
+    return v | dpp_mov<DPP_XOR1>(v);
+}
+template <int LC>
+__device__ __forceinline__ float group_pick(float mine, bool chosen) {
+    return __uint_as_float(group_or<LC>(chosen ? __float_as_uint(mine) : 0u));
+}
+template <int LC>
+__device__ __forceinline__ double group_pick(double mine, bool chosen) {
+    const unsigned hi = group_or<LC>(chosen ? (unsigned)__double2hiint(mine) : 0u);
+    const unsigned lo = group_or<LC>(chosen ? (unsigned)__double2loint(mine) : 0u);
+    return __hiloint2double((int)hi, (int)lo);
 }
 
 // max over the valid columns of this lane's 4 elements, reduced over the group (-inf if none).
@@ -166,12 +218,23 @@ __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4
     }
     const int cnt = __popc(f);
     int incl = cnt;
+    int total;
+    if constexpr (dpp_width(LC)) {
+        int t = dpp_mov<DPP_SHR1>(incl);
+        if (sub >= 1) incl += t;
+        if constexpr (LC == 4) {
+            t = dpp_mov<DPP_SHR2>(incl);
+            if (sub >= 2) incl += t;
+        }
+        total = group_bcast<LC, LC - 1>(incl, L);
+    } else {
 #pragma unroll
-    for (int off = 1; off < L; off <<= 1) {
-        const int t = __shfl_up(incl, off, L);
-        if (sub >= off) incl += t;
+        for (int off = 1; off < L; off <<= 1) {
+            const int t = __shfl_up(incl, off, L);
+            if (sub >= off) incl += t;
+        }
+        total = __shfl(incl, L - 1, L);
     }
-    const int total = __shfl(incl, L - 1, L);
     int act = -1;
     if (total > 0) {
         const int k = (int)mulhi32(explore ? x1 : x2, (uint32_t)total);
@@ -185,7 +248,9 @@ __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4
     act = group_max_int<LC>(act, L);
     const int jj = act & 3;
     const T mine = jj == 0 ? row.v[0] : (jj == 1 ? row.v[1] : (jj == 2 ? row.v[2] : row.v[3]));
-    *picked_q = __shfl(mine, act < 0 ? 0 : (act >> 2), L);
+    const int holder = act < 0 ? 0 : (act >> 2);
+    if constexpr (dpp_width(LC)) *picked_q = group_pick<LC>(mine, sub == holder);
+    else *picked_q = __shfl(mine, holder, L);
     return act;
 }
 

@@ -859,7 +859,7 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
     // table slots of steps t-1 / t-2.  Lane 0 of a group owns the row-s slot; the row-n slot is owned
     // by lane 1 (slot) when the group has two or more lanes, by lane 0 (slot2) otherwise.
     int cur_slot = -1, prev_slot = -1, cur_slot2 = -1, prev_slot2 = -1;
-    const int flush_every = EP_STAGE / 2 / (int)c.N > 0 ? EP_STAGE / 2 / (int)c.N : 1;
+    const int flush_every = 32;  // steps per flush window of the staged episode log
     int flush_in = flush_every;
     for (int k = tid; k < 3 * CT_SLOTS; k += (int)blockDim.x) {
         (&lds.ct_key[0][0])[k] = -1;
@@ -926,7 +926,9 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                     cn = lds.ct_cnt[tb][ns]; mn = lds.ct_min[tb][ns]; has_n = 1;
                 }
             }
-            if (two) { cn = __shfl(cn, 1, L); mn = __shfl(mn, 1, L); has_n = __shfl(has_n, 1, L); }
+            if (two) {
+                cn = group_bcast<LC, 1>(cn, L); mn = group_bcast<LC, 1>(mn, L); has_n = group_bcast<LC, 1>(has_n, L);
+            }
             if (lead) {
                 const unsigned cs = lds.ct_cnt[tb][cur_slot];
                 const int ms = lds.ct_min[tb][cur_slot];
@@ -957,7 +959,7 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                     if (cx) lds.complex_ = 1u;
                 }
             }
-            if (LC != 1) cls = __shfl(cls, 0, L);
+            if (LC != 1) cls = group_bcast<LC, 0>(cls, L);
         }
         QE_STAMP(2);
         // ---- Philox draws of select(t+1): independent of memory, computed under the row gather.
@@ -977,7 +979,17 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                 batch = philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)stepk, (uint32_t)(stepk >> 32),
                                       STREAM_POLICY, c.seed_lo, c.seed_hi);
             }
-            x.x = __shfl(batch.x, phase, LB); x.y = __shfl(batch.y, phase, LB); x.z = __shfl(batch.z, phase, LB);
+            // `phase` is uniform, so the block is fetched from its lane with a DPP broadcast chosen by a
+            // scalar branch (LB lanes = one quad or half a quad)
+            auto fetch = [&](auto k) {
+                constexpr int K = decltype(k)::value;
+                x.x = group_bcast<LB, K>(batch.x, LB); x.y = group_bcast<LB, K>(batch.y, LB);
+                x.z = group_bcast<LB, K>(batch.z, LB);
+            };
+            if (phase == 0) fetch(std::integral_constant<int, 0>{});
+            else if (phase == 1) fetch(std::integral_constant<int, 1>{});
+            else if (phase == 2) fetch(std::integral_constant<int, LB == 4 ? 2 : 0>{});
+            else fetch(std::integral_constant<int, LB == 4 ? 3 : 1>{});
             x.w = 0u;
         }
         const float r_t = p.r;
@@ -1003,9 +1015,18 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
             acc += r_t;
             if (term_t) {
                 if (sub == 0 && (flags & FLAG_ACCOUNT)) {
+                    // entry k of this flush window lands at log position ep_base + k: through the LDS
+                    // stage normally, straight to memory when more episodes end in one window than
+                    // the stage holds (never happens at the usual termination rates)
                     const unsigned k = atomicAdd(&lds.ep_n, 1u);
-                    lds.ep_key[k] = ((unsigned long long)t << 32) | (unsigned long long)i;
-                    lds.ep_ret[k] = acc;
+                    const unsigned long long key = ((unsigned long long)t << 32) | (unsigned long long)i;
+                    if (k < (unsigned)EP_STAGE) {
+                        lds.ep_key[k] = key;
+                        lds.ep_ret[k] = acc;
+                    } else if ((long long)(ep_base + k) < c.ep_cap) {
+                        c.ep_key[ep_base + k] = key;
+                        c.ep_ret[ep_base + k] = acc;
+                    }
                 }
                 acc = 0.0f;
             }
@@ -1038,7 +1059,7 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                     if (tid == 0) lds.n_rem = (unsigned)n_def;
                     __syncthreads();
                     bool mine = active && !(cls & 1);
-                    if (LC != 1) { pred_s = __shfl(pred_s, 0, L); pred_n = __shfl(pred_n, 0, L); }
+                    if (LC != 1) { pred_s = group_bcast<LC, 0>(pred_s, L); pred_n = group_bcast<LC, 0>(pred_n, L); }
                     int rounds = 0;
                     while (lds.n_rem > 0u && rounds++ <= n_def) {
                         const bool go = mine && (pred_s < 0 || lds.pending[pred_s] == 0) &&
@@ -1074,11 +1095,11 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
             if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }
         }
         // ---- bulk flush of the staged episode log (uniform, data-independent decision) ----------
-        if (--flush_in == 0 || last) {  // at most flush_every * N <= EP_STAGE / 2 entries staged
+        if (--flush_in == 0 || last) {
             flush_in = flush_every;
             __syncthreads();
             const unsigned staged = lds.ep_n;
-            for (unsigned k = tid; k < staged; k += blockDim.x) {
+            for (unsigned k = tid; k < min(staged, (unsigned)EP_STAGE); k += blockDim.x) {
                 const unsigned long long pos = ep_base + k;
                 if ((long long)pos < c.ep_cap) { c.ep_key[pos] = lds.ep_key[k]; c.ep_ret[pos] = lds.ep_ret[k]; }
             }
