@@ -390,8 +390,15 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     if (persistent) {
         const unsigned block = (unsigned)((lanes + 63) / 64 * 64);
         auto go = [&](auto lc) {
-            hipLaunchKernelGGL((k_rollout_persistent<T, Env, decltype(lc)::value>), dim3(1), dim3(block), 0,
-                               e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+            constexpr int LCV = decltype(lc)::value;
+            // up to 512 threads the kernel is built with twice the vector-register budget (the BASELINE
+            // shapes with 128 agents: 256 or 512 lanes)
+            if ((LCV == 2 || LCV == 4) && block <= 512)
+                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, (LCV == 2 || LCV == 4) ? 512 : 1024>), dim3(1),
+                                   dim3(block), 0, e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+            else
+                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, 1024>), dim3(1), dim3(block), 0,
+                                   e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
         };
         if constexpr (std::is_same<Env, HashEnv>::value) {
             switch (e->L) {  // compile-time lane-group width: reductions become DPP moves

@@ -207,14 +207,14 @@ __device__ __forceinline__ void advance_regs(const Ctx<T>& c, const EnvCtx& ev, 
 }
 
 // same, with the agent state kept in the global arrays (step-wise kernels)
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __device__ __forceinline__ void advance_agent(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
                                               int32_t n, Row4<T>& row, uint32_t valid, long long t1,
                                               int flags) {
     Pending<T> p;
     p.n = n;
     p.aux = c.aux[i];
-    advance_regs<T, Env>(c, ev, i, sub, row, valid, t1, flags, p);
+    advance_regs<T, Env, LC>(c, ev, i, sub, row, valid, t1, flags, p);
     if (sub == 0) {
         c.s[i] = p.s; c.a[i] = p.a; c.pred[i] = p.pred; c.r[i] = p.r;
         c.term[i] = p.term ? 1 : 0; c.n[i] = p.n; c.aux[i] = p.aux;
@@ -357,14 +357,14 @@ __device__ __forceinline__ LiveAgent<T> live_agent(const Ctx<T>& c, int64_t i) {
 }
 
 // learn(t) for one involved agent; all L lanes of a group call it.
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __device__ __forceinline__ void ordered_learn(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
                                               long long t) {
     const LiveAgent<T> g = live_agent(c, i);
     T m = 0;
     if (!g.term) {
         const Row4<T> row = load_row4(c.q, g.n, c.ld, sub);
-        m = row_max_valid(row, Env::valid4(ev, i, g.n, sub), c.L);
+        m = row_max_valid<LC>(row, Env::valid4(ev, i, g.n, sub), c.L);
     }
     if (sub == 0) {
         const int64_t cell = (int64_t)g.s * c.ld + g.a;
@@ -386,7 +386,7 @@ __device__ __forceinline__ void barrier_lds() {
 
 // learn(t) for the involved agent staged at list position `pos`, entirely out of LDS (row cache lines
 // `is` / `in`); the new cell value is written to the cache and through to the table.
-template <typename T, class Env, class Lds>
+template <typename T, class Env, int LC = 0, class Lds>
 __device__ __forceinline__ void ordered_learn_cached(const Ctx<T>& c, const EnvCtx& ev, Lds& lds, int pos,
                                                      int sub, long long t, const Hyper& h, T* cache, int is,
                                                      int in) {
@@ -399,7 +399,7 @@ __device__ __forceinline__ void ordered_learn_cached(const Ctx<T>& c, const EnvC
         const T* src = cache + (int64_t)in * c.ld + 4 * sub;
 #pragma unroll
         for (int j = 0; j < 4; ++j) row.v[j] = 4 * sub < c.ld ? src[j] : neg_inf<T>();
-        m = row_max_valid(row, Env::valid4(ev, i, n, sub), c.L);
+        m = row_max_valid<LC>(row, Env::valid4(ev, i, n, sub), c.L);
     }
     if (sub == 0) {
         T* cell = cache + (int64_t)is * c.ld + a;
@@ -435,7 +435,7 @@ __device__ int build_involved_list(const Ctx<T>& c, int* scan) {
     return base;
 }
 
-template <typename T, class Env, int CAP, int CACHE_BYTES>
+template <typename T, class Env, int CAP, int CACHE_BYTES, int LC = 0>
 __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long long t, const int M_all,
                           SlowLdsT<CAP, CACHE_BYTES>& lds) {
     constexpr int HASH = 4 * CAP;
@@ -465,7 +465,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                 const int64_t i = c.inv_list[pos];
                 const LiveAgent<T> g = live_agent(c, i);
                 const Row4<T> row = load_row4(c.q, g.n, c.ld, sub);
-                const T m = row_max_valid(row, Env::valid4(ev, i, g.n, sub), L);
+                const T m = row_max_valid<LC>(row, Env::valid4(ev, i, g.n, sub), L);
                 if (sub == 0) {
                     const int64_t cell = (int64_t)g.s * c.ld + g.a;
                     const T q0 = c.q[cell];
@@ -617,7 +617,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                     const T* src = cache + (int64_t)in * c.ld + 4 * sub;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) row.v[j] = 4 * sub < c.ld ? src[j] : neg_inf<T>();
-                    m_mine = row_max_valid(row, valid, L);
+                    m_mine = row_max_valid<LC>(row, valid, L);
                 }
                 m_known = true;
                 if (sub == 0) { lds.a_m[pos] = (double)m_mine; lds.a_mready[pos] = 1; }
@@ -637,7 +637,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                             const T* src = cache + (int64_t)in * c.ld + 4 * sub;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) row.v[j] = 4 * sub < c.ld ? src[j] : neg_inf<T>();
-                            m = row_max_valid(row, valid, L);
+                            m = row_max_valid<LC>(row, valid, L);
                         }
                         // The lane group then runs AHEAD along the chain of later agents that update the
                         // SAME cell (many agents in one state taking the greedy action) as long as they
@@ -699,10 +699,10 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                 if (go) {
                     if (cached) {
                         const int is = lds.h_row[ss];
-                        ordered_learn_cached<T, Env>(c, ev, lds, pos, sub, t, hyper, cache, is,
+                        ordered_learn_cached<T, Env, LC>(c, ev, lds, pos, sub, t, hyper, cache, is,
                                                      sn >= 0 ? (int)lds.h_row[sn] : is);
                     } else {
-                        ordered_learn<T, Env>(c, ev, list[pos], sub, t);
+                        ordered_learn<T, Env, LC>(c, ev, list[pos], sub, t);
                     }
                     if (sub == 0) lds.a_state[pos] = 2;
                 }
@@ -749,7 +749,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                 const int64_t i = c.inv_list[pos];
                 const int32_t n = c.n[i];
                 Row4<T> row = load_row4(c.q, n, c.ld, sub);
-                advance_agent<T, Env>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
+                advance_agent<T, Env, LC>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
             }
         }
     }
@@ -808,6 +808,7 @@ struct PersistLds {
     unsigned long long ep_key[EP_STAGE];
     float ep_ret[EP_STAGE];
     unsigned char pending[PERSIST_MAX_AGENTS];  // 1 while an agent's deferred update is outstanding
+    alignas(16) unsigned char cold[320];  // the launch context, for the rare paths (see the kernel)
     unsigned busy[3];     // step t: some row has more than one toucher
     unsigned ep_n;
     unsigned n_def;       // agents whose update is deferred in this step
@@ -833,8 +834,8 @@ __device__ __forceinline__ int ct_insert(PersistLds& l, int tb, int32_t row, uns
 #define QE_STAMP(k) do { } while (0)
 #endif
 
-template <typename T, class Env, int LC>
-__global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev, long long steps, int flags) {
+template <typename T, class Env, int LC, int BLOCK = 1024>
+__global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx ev, long long steps, int flags) {
     __shared__ PersistLds lds;
 #ifdef QE_STAMPS
     long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -867,7 +868,12 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
         (&lds.ct_min[0][0])[k] = 0x7FFFFFFF;
     }
     for (int k = tid; k < PERSIST_MAX_AGENTS; k += (int)blockDim.x) lds.pending[k] = 0;
+    // The context is ~70 scalar registers; what only the rare paths need (agent arrays for the general
+    // ordered path, log pointers for the periodic flush, the epilogue) is parked in LDS and fetched
+    // when such a path runs, so that the quiet step does not pay for scalar-register spills.
+    static_assert(sizeof(Ctx<T>) <= sizeof(lds.cold), "context stash too small");
     if (tid == 0) {
+        *reinterpret_cast<Ctx<T>*>(lds.cold) = c;
         lds.ep_n = 0u; lds.n_def = 0u; lds.n_rem = 0u; lds.complex_ = 0u;
         lds.busy[0] = lds.busy[1] = lds.busy[2] = 0u;
         c.ctrl->error = 0u;  // this launch owns the control block: no host-side memset in front of it
@@ -1023,9 +1029,12 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                     if (k < (unsigned)EP_STAGE) {
                         lds.ep_key[k] = key;
                         lds.ep_ret[k] = acc;
-                    } else if ((long long)(ep_base + k) < c.ep_cap) {
-                        c.ep_key[ep_base + k] = key;
-                        c.ep_ret[ep_base + k] = acc;
+                    } else {
+                        const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+                        if ((long long)(ep_base + k) < cc.ep_cap) {
+                            cc.ep_key[ep_base + k] = key;
+                            cc.ep_ret[ep_base + k] = acc;
+                        }
                     }
                 }
                 acc = 0.0f;
@@ -1045,15 +1054,24 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                 deferred_total += (unsigned long long)n_def;
                 if (lds.complex_) {
                     // general case: hand the deferred transitions to slow_body through the arrays
+                    // hot fields from the kernel arguments, the parked ones from LDS; the step-wise
+                    // kernels' contention structures do not exist in this kernel
+                    const Ctx<T>& cold = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+                    Ctx<T> cc = c;
+                    cc.s = cold.s; cc.a = cold.a; cc.n = cold.n; cc.r = cold.r; cc.term = cold.term;
+                    cc.pred = cold.pred; cc.aux = cold.aux; cc.acc = cold.acc;
+                    cc.inv_bitmap = cold.inv_bitmap; cc.inv_list = cold.inv_list; cc.vinc = cold.vinc;
+                    cc.ctrl = cold.ctrl; cc.ep_key = cold.ep_key; cc.ep_ret = cold.ep_ret; cc.ep_cap = cold.ep_cap;
+                    cc.stamps = nullptr; cc.tok = nullptr; cc.adv_bitmap = nullptr; cc.pend_list = nullptr;
                     if (lead && !(cls & 1)) {
-                        c.s[i] = p.s; c.a[i] = p.a; c.pred[i] = p.pred; c.r[i] = p.r;
-                        c.term[i] = p.term ? 1 : 0; c.n[i] = p.n; c.aux[i] = p.aux;
-                        atomicOr(&c.inv_bitmap[i >> 5], 1u << (i & 31));
+                        cc.s[i] = p.s; cc.a[i] = p.a; cc.pred[i] = p.pred; cc.r[i] = p.r;
+                        cc.term[i] = p.term ? 1 : 0; cc.n[i] = p.n; cc.aux[i] = p.aux;
+                        atomicOr(&cc.inv_bitmap[i >> 5], 1u << (i & 31));
                         lds.pending[i] = 0;
                     }
                     __syncthreads();
-                    (void)build_involved_list(c, lds.slow.scan);  // == n_def agents
-                    slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES>(c, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
+                    (void)build_involved_list(cc, lds.slow.scan);  // == n_def agents
+                    slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES, LC>(cc, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
                     __syncthreads();
                 } else {
                     if (tid == 0) lds.n_rem = (unsigned)n_def;
@@ -1084,7 +1102,7 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
                         }
                         __syncthreads();  // this round's table writes are complete and visible
                     }
-                    if (tid == 0 && lds.n_rem > 0u) c.ctrl->error = 2u;
+                    if (tid == 0 && lds.n_rem > 0u) reinterpret_cast<const Ctx<T>*>(lds.cold)->ctrl->error = 2u;
                 }
             }
             // every update of step t is in the table: late selections read their row again
@@ -1099,9 +1117,13 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
             flush_in = flush_every;
             __syncthreads();
             const unsigned staged = lds.ep_n;
+            const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+            unsigned long long* const out_key = cc.ep_key;
+            float* const out_ret = cc.ep_ret;
+            const long long out_cap = cc.ep_cap;
             for (unsigned k = tid; k < min(staged, (unsigned)EP_STAGE); k += blockDim.x) {
                 const unsigned long long pos = ep_base + k;
-                if ((long long)pos < c.ep_cap) { c.ep_key[pos] = lds.ep_key[k]; c.ep_ret[pos] = lds.ep_ret[k]; }
+                if ((long long)pos < out_cap) { out_key[pos] = lds.ep_key[k]; out_ret[pos] = lds.ep_ret[k]; }
             }
             ep_base += staged;
             __syncthreads();
@@ -1113,11 +1135,12 @@ __global__ __launch_bounds__(1024) void k_rollout_persistent(Ctx<T> c, EnvCtx ev
 #ifdef QE_STAMPS
     if (tid == 0 && c.vinc) for (int k = 0; k < 8; ++k) c.vinc[k] = (double)stamp_sum[k];
 #endif
-    if (lead) { c.n[i] = p.n; c.aux[i] = p.aux; c.acc[i] = acc; }
+    const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+    if (lead) { cc.n[i] = p.n; cc.aux[i] = p.aux; cc.acc[i] = acc; }
     if (tid == 0) {
-        c.ctrl->involved_total = deferred_total;
-        c.ctrl->ep_count = ep_base;
-        c.ctrl->t_local = steps;
+        cc.ctrl->involved_total = deferred_total;
+        cc.ctrl->ep_count = ep_base;
+        cc.ctrl->t_local = steps;
     }
 }
 
