@@ -622,6 +622,7 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     // tuning overrides for experiments (same meaning as the qe_set_option knobs; results never change)
     if (const char* v = getenv("QE_TOKEN_ROUNDS")) e->opt_rounds = std::max(0, std::min(MAX_TOKEN_ROUNDS, atoi(v)));
     if (const char* v = getenv("QE_LISTED_MIN_AGENTS")) e->listed_min = std::max(1, atoi(v));
+    if (const char* v = getenv("QE_USE_GRAPH")) e->opt_graph = atoi(v) != 0;  // rocprofv3 crashes on graph replay
     const size_t bytes = (size_t)S * e->ld * e->esize();
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);

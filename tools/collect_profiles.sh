@@ -1,0 +1,28 @@
+#!/usr/bin/env bash
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel statistics and the separate PMC passes that
+# bench.py's roofline block and profiles/ are built from.  Usage: tools/collect_profiles.sh <tag>
+# Output: gpurun_out/prof_<tag>/...; summarise locally with tools/summarise_profiles.py <tag>.
+set -uo pipefail
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 20000 --warmup 2000 --no-cpu-baseline"
+if [ "${SKIP_HEADLINE:-0}" != 1 ]; then
+# 1. kernel trace + stats, headline (the program itself after --, no wrapper)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/headline_stats" -- $BENCH > "$OUT/headline_stats.log" 2>&1 || exit 1
+# 2. PMC passes, one counter group per run, kernel-trace only
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    name=$(echo "$grp" | tr ' ' '_')
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/headline_pmc_$name" -- $BENCH > "$OUT/headline_pmc_$name.log" 2>&1 || exit 1
+done
+fi
+# 3. kernel stats of the step-wise / wide shapes (eager launches: rocprofv3 7.2 segfaults when a
+#    captured HIP graph is replayed under --kernel-trace; kernel durations are the same either way)
+export QE_USE_GRAPH=0
+for wl in c3 c5 wide; do
+    steps=4000; [ "$wl" = wide ] && steps=400
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${wl}_stats" -- python3 $ROOT/bench.py --workload $wl --steps $steps --warmup 4000 --no-cpu-baseline > "$OUT/${wl}_stats.log" 2>&1 || exit 1
+done
+echo "profiles collected under $OUT"

@@ -1,0 +1,67 @@
+"""Turn gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the files kept under profiles/."""
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = Path("gpurun_out") / f"prof_{tag}"
+dst = Path("profiles")
+
+
+def one(pattern):
+    hits = glob.glob(str(src / pattern), recursive=True)
+    if not hits:
+        raise SystemExit(f"missing {pattern}")
+    return hits[0]
+
+
+def bench_line(log):
+    for line in open(log):
+        if line.startswith('{"metric"'):
+            return json.loads(line)
+    raise SystemExit(f"no bench line in {log}")
+
+
+for wl in ("headline", "c3", "c5", "wide"):
+    shutil.copy(one(f"{wl}_stats/**/*kernel_stats.csv"), dst / f"{tag}_{wl}_kernel_stats.csv")
+    json.dump(bench_line(src / f"{wl}_stats.log"), open(dst / f"{tag}_{wl}_bench_under_rocprof.json", "w"), indent=1)
+
+
+def pmc_sum(group, counter, kernel_substr):
+    total, launches = 0.0, 0
+    for row in csv.DictReader(open(one(f"headline_pmc_{group}/**/*counter_collection.csv"))):
+        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            total += float(row["Counter_Value"])
+            launches += 1
+    return total, launches
+
+
+kern = "k_rollout_persistent"
+fetch, n1 = pmc_sum("FETCH_SIZE", "FETCH_SIZE", kern)
+write, _ = pmc_sum("WRITE_SIZE", "WRITE_SIZE", kern)
+hit, _ = pmc_sum("TCC_HIT_sum_TCC_MISS_sum", "TCC_HIT_sum", kern)
+miss, _ = pmc_sum("TCC_HIT_sum_TCC_MISS_sum", "TCC_MISS_sum", kern)
+line = bench_line(src / "headline_stats.log")
+env_steps = (line["steps"] + line["warmup"]) * line["config"]["agents_per_gpu"]  # all launches of the process
+traffic = 2.0 * fetch * 1024 + write * 1024  # KB counters; gfx950 FETCH_SIZE halves 16-B-per-lane loads
+out = {
+    "headline": {
+        "command": "rocprofv3 --kernel-trace --pmc <counter group> --output-format csv -- python3 bench.py --steps 20000 "
+                   "--warmup 2000 --no-cpu-baseline (one pass per group: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)",
+        "kernel": "k_rollout_persistent<float, HashEnv, 4, 512>",
+        "launches": n1,
+        "env_steps_all_launches": env_steps,
+        "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
+        "l2_hit_rate": hit / max(1.0, hit + miss),
+        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for 16-B-per-lane loads "
+                      "(MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE taken as is",
+        "traffic_bytes_all_launches": traffic,
+        "traffic_bytes_per_env_step": traffic / env_steps,
+        "algorithmic_bytes_per_env_step": line["roofline"]["alg_bytes_per_env_step"],
+    }
+}
+json.dump(out, open(dst / f"{tag}_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
