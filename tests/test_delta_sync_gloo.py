@@ -100,3 +100,61 @@ def test_two_rank_replica_sync_matches_single_process_simulation(tmp_path, overl
     assert np.count_nonzero(q0) > 100
     assert np.allclose(q0, q1, rtol=1e-5, atol=1e-6)  # same sums, different fp32 summation order
     assert not np.array_equal(np.load(tmp_path / "obs0.npy"), np.load(tmp_path / "obs1.npy"))
+
+
+# ------------------------------------------------------------------------------------------------
+# with an exchange after EVERY step (and no overlap) the replica protocol is
+# single-process `learn_vec` over all agents, up to the order in which increments are added.
+K1_STEPS = 6
+
+
+def _worker_every_step(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dist_classicrl_amd.distributed.delta_sync import DeltaSync
+    from oracle import c_oracle
+
+    run = c_oracle.CHashRollout(N_PER_RANK, S, A, agent_offset=rank * N_PER_RANK, dtype=np.float32, mode="vec")
+
+    def apply_fn(entries, count):
+        e = entries[:count].numpy()
+        _apply(run.q, e[:, 0], e[:, 1].view(np.float32))
+
+    sync = DeltaSync(N_PER_RANK, "cpu", apply_fn, overlap=False)
+    eps, _ = c_oracle.exp_schedule(0.3, 0.3, 1.0, 2 * N_PER_RANK, K1_STEPS)
+    lr, _ = c_oracle.exp_schedule(0.1, 0.1, 1.0, 2 * N_PER_RANK, K1_STEPS)
+    actions = []
+    for t in range(K1_STEPS):
+        before = run.q.copy()
+        out = run.run(eps[t:t + 1], lr[t:t + 1], trace=True, log_episodes=False)
+        actions.append(out["actions"][0])
+        cells = np.flatnonzero((run.q != before).ravel()).astype(np.int32)
+        deltas = (run.q.ravel()[cells] - before.ravel()[cells]).astype(np.float32)
+        log = sync.log
+        log.zero_()
+        log[:cells.size, 0] = torch.from_numpy(cells)
+        log[:cells.size, 1] = torch.from_numpy(deltas.view(np.int32))
+        sync.exchange(N_PER_RANK)  # padded with (cell 0, +0.0) no-ops
+    np.save(os.path.join(out_dir, f"k1_q{rank}.npy"), run.q)
+    np.save(os.path.join(out_dir, f"k1_a{rank}.npy"), np.stack(actions))
+    dist.destroy_process_group()
+
+
+def test_exchange_every_step_equals_learn_vec_over_all_agents(tmp_path):
+    from oracle import c_oracle
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_every_step, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    whole = c_oracle.CHashRollout(2 * N_PER_RANK, S, A, dtype=np.float32, mode="vec")
+    eps, _ = c_oracle.exp_schedule(0.3, 0.3, 1.0, 2 * N_PER_RANK, K1_STEPS)
+    lr, _ = c_oracle.exp_schedule(0.1, 0.1, 1.0, 2 * N_PER_RANK, K1_STEPS)
+    ref = whole.run(eps, lr, trace=True, log_episodes=False)
+    got_actions = np.concatenate([np.load(tmp_path / "k1_a0.npy"), np.load(tmp_path / "k1_a1.npy")], axis=1)
+    assert np.array_equal(got_actions, ref["actions"])  # same agents, same draws, same policy
+    for r in (0, 1):
+        q = np.load(tmp_path / f"k1_q{r}.npy")
+        # float32 deltas added in a different order than np.add.at: 1e-6 relative per increment
+        assert np.allclose(q, whole.q, rtol=2e-6, atol=1e-7)
+    assert np.count_nonzero(whole.q) > 100
