@@ -108,6 +108,12 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: libraries that print banners to file
+    # descriptor 1 (RCCL does at communicator creation) are sent to stderr until the line is printed
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     wl = WORKLOADS[args.workload]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -235,7 +241,9 @@ def main() -> None:
             line["value"] / PUBLISHED_TICTACTOE_SINGLE_THREAD_128)
     if use_dist:
         line["delta_sync"] = {"syncs": rt.delta_sync.syncs, "bytes_received_per_gpu": rt.delta_sync.bytes_exchanged}
-    print(json.dumps(line))
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "qe_env_step": (C.c_int, [_P, _I32P, _I32P, _F32P, _U8P, _U8P]),
     "qe_rollout": (C.c_int, [_P, _P, C.c_int64, _F64P, _F64P, C.c_int32, _I32P, C.POINTER(RolloutStats)]),
     "qe_rollout_begin": (C.c_int, [_P, _P, C.c_int64, _F64P, _F64P, C.c_int32, C.c_int32]),
+    "qe_schedule_plan": (C.c_int, [_P, _F64P, _F64P, C.c_int64]),
     "qe_rollout_end": (C.c_int, [_P, C.c_int32, C.POINTER(RolloutStats)]),
     "qe_evaluate": (C.c_int, [_P, _P, C.c_int64, C.POINTER(RolloutStats)]),
     "qe_episode_log": (C.c_int64, [_P, C.c_int64, _I32P, _I32P, _F32P]),
@@ -101,6 +102,7 @@ PROTOTYPES = {
     "qe_delta_log_count": (C.c_int64, [_P]),
     "qe_delta_log_reset": (C.c_int, [_P]),
     "qe_delta_apply_dev": (C.c_int, [_P, _P, C.c_int64]),
+    "qe_delta_apply_skip_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64]),
 }
 
 _lib = None

@@ -108,11 +108,14 @@ class GpuRolloutQLearning(BaseRuntime):
             sizes = [min(chunk_max, steps - d) for d in range(0, steps, chunk_max)]
             starts = np.cumsum([0] + sizes[:-1])
 
+            # the schedule values of the whole call go to the device once (qe_schedule_plan); the chunks
+            # consume them in order
+            eps = _schedule_values(self.exploration_rate_schedule, n, steps)
+            lr = _schedule_values(self.lr_schedule, n, steps)
+            _lib.check(lib.qe_schedule_plan(algo.handle, _lib.ptr(eps, C.c_double), _lib.ptr(lr, C.c_double), steps))
+
             def begin(k):
-                eps = _schedule_values(self.exploration_rate_schedule, n, sizes[k])
-                lr = _schedule_values(self.lr_schedule, n, sizes[k])
-                _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, sizes[k], _lib.ptr(eps, C.c_double),
-                                                _lib.ptr(lr, C.c_double), mode, k & 1))
+                _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, sizes[k], None, None, mode, k & 1))
 
             def end(k):
                 st = _lib.RolloutStats()

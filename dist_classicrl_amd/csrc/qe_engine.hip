@@ -144,6 +144,7 @@ struct RolloutSlot {
     int32_t* trace_host = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int rounds = 4;  // token rounds per step of this call (wide mode)
+    int64_t plan_offset = -1;  // >= 0: schedules come from the engine's plan at this offset
     double* dbg = nullptr;  // env->vinc of the rollout in flight (diagnostic builds)
     void release() {
         if (ctrl) (void)hipFree(ctrl);
@@ -200,6 +201,13 @@ struct qe_engine {
     DeltaEntry* dlog = nullptr;
     long long dlog_cap = 0, dlog_count = 0;
     DevBuf<int32_t> trace;
+    // schedule plan (qe_schedule_plan): values of a whole training call, consumed by the rollouts
+    DevBuf<unsigned long long> plan_thr;
+    DevBuf<double> plan_lr;
+    PinnedBuf<unsigned long long> h_plan_thr;
+    PinnedBuf<double> h_plan_lr;
+    int64_t plan_count = 0, plan_cursor = 0;
+    hipEvent_t plan_ready = nullptr;
     hipStream_t copy_stream = nullptr;  // result read-back beside the compute stream
     RolloutSlot slots[2];               // two rollouts may be in flight (begin k+1 before end k)
     size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
@@ -264,7 +272,7 @@ unsigned long long eps_threshold(double eps) {
     return v >= 4294967296.0 ? (1ull << 32) : (unsigned long long)v;
 }
 
-int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps, const double* lr) {
+int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps, const double* lr, bool use_plan) {
     if (!sl.ctrl) {
         HIP_TRY(hipMalloc((void**)&sl.ctrl, sizeof(Ctrl)));
         HIP_TRY(hipEventCreate(&sl.ev0));
@@ -273,6 +281,12 @@ int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps
         HIP_TRY(sl.ep_key.ensure((size_t)e->ep_cap));
         HIP_TRY(sl.ep_ret.ensure((size_t)e->ep_cap));
         HIP_TRY(sl.h_ctrl.ensure(1));
+    }
+    sl.plan_offset = -1;
+    if (use_plan) {  // the values are already on the device
+        sl.plan_offset = e->plan_cursor;
+        e->plan_cursor += steps;
+        return QE_OK;
     }
     HIP_TRY(sl.h_thr.ensure((size_t)steps));
     HIP_TRY(sl.h_lr.ensure((size_t)steps));
@@ -352,6 +366,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     Ctx<T> c = env_ctx<T>(e, env);
     c.mode = mode;
     c.ctrl = sl.ctrl; c.thr = sl.thr.p; c.lr = sl.lr.p;
+    if (sl.plan_offset >= 0) { c.thr = e->plan_thr.p + sl.plan_offset; c.lr = e->plan_lr.p + sl.plan_offset; }
     c.ep_key = sl.ep_key.p; c.ep_ret = sl.ep_ret.p; c.ep_cap = e->ep_cap;
     const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
     if (trace_host) {
@@ -656,6 +671,8 @@ int qe_destroy(qe_engine* e) {
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     e->slots[0].release(); e->slots[1].release();
+    if (e->plan_ready) (void)hipEventDestroy(e->plan_ready);
+    e->plan_thr.release(); e->plan_lr.release(); e->h_plan_thr.release(); e->h_plan_lr.release();
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     e->thr.release(); e->lr.release(); e->b_s.release(); e->b_a.release(); e->b_n.release();
     e->b_out.release(); e->b_list.release(); e->b_r.release(); e->b_acc.release(); e->b_term.release();
@@ -1009,12 +1026,16 @@ static int begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, co
     if (!e || !env || env->e != e) return fail(QE_ERR_INVALID, "engine/env mismatch");
     if (slot < 0 || slot > 1) return fail(QE_ERR_INVALID, "slot must be 0 or 1");
     if (steps <= 0) return fail(QE_ERR_INVALID, "steps must be > 0");
-    if (learn && (!eps || !lr)) return fail(QE_ERR_INVALID, "eps and lr schedules are required");
+    const bool use_plan = learn && !eps && !lr;
+    if (use_plan && e->plan_cursor + steps > e->plan_count)
+        return fail(QE_ERR_INVALID, "schedule plan exhausted: %lld values left, %lld steps requested",
+                    (long long)(e->plan_count - e->plan_cursor), (long long)steps);
+    if (learn && !use_plan && (!eps || !lr)) return fail(QE_ERR_INVALID, "eps and lr schedules are required");
     if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
     RolloutSlot& sl = e->slots[slot];
     if (sl.busy) return fail(QE_ERR_INVALID, "slot %d still has a rollout in flight (call qe_rollout_end)", slot);
     HIP_TRY(hipSetDevice(e->device));
-    if (int rc = slot_prepare(e, sl, steps, learn ? eps : nullptr, learn ? lr : nullptr)) return rc;
+    if (int rc = slot_prepare(e, sl, steps, learn ? eps : nullptr, learn ? lr : nullptr, use_plan)) return rc;
     return e->dtype == QE_F32 ? rollout_begin_dispatch<float>(e, env, sl, steps, mode, learn, trace)
                               : rollout_begin_dispatch<double>(e, env, sl, steps, mode, learn, trace);
 }
@@ -1022,6 +1043,31 @@ static int begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, co
 int qe_rollout_begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
                      int32_t mode, int32_t slot) {
     return begin(e, env, steps, eps, lr, mode, 1, nullptr, slot);
+}
+
+int qe_schedule_plan(qe_engine* e, const double* eps, const double* lr, int64_t count) {
+    if (!e || count < 0 || (count > 0 && (!eps || !lr))) return fail(QE_ERR_INVALID, "bad argument");
+    if (e->slots[0].busy || e->slots[1].busy) return fail(QE_ERR_INVALID, "a rollout is in flight");
+    HIP_TRY(hipSetDevice(e->device));
+    // (no rollout in flight = every kernel that read the previous plan has completed: qe_rollout_end
+    // waited for it.  No host synchronisation here: on ROCm 7.2 a hipStreamSynchronize + H2D copy on
+    // the compute stream at this point was measured at 7 ms.)
+    e->plan_count = 0; e->plan_cursor = 0;
+    if (count == 0) return QE_OK;
+    // sized generously and doubled when outgrown: re-allocating pinned memory costs milliseconds
+    size_t cap = std::max<size_t>(e->plan_thr.cap, (size_t)1 << 16);
+    while (cap < (size_t)count) cap *= 2;
+    HIP_TRY(e->h_plan_thr.ensure(cap)); HIP_TRY(e->h_plan_lr.ensure(cap));
+    HIP_TRY(e->plan_thr.ensure(cap)); HIP_TRY(e->plan_lr.ensure(cap));
+    for (int64_t t = 0; t < count; ++t) e->h_plan_thr.p[t] = eps_threshold(eps[t]);
+    memcpy(e->h_plan_lr.p, lr, (size_t)count * sizeof(double));
+    if (!e->plan_ready) HIP_TRY(hipEventCreateWithFlags(&e->plan_ready, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(e->plan_thr.p, e->h_plan_thr.p, count * sizeof(unsigned long long), hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipMemcpyAsync(e->plan_lr.p, e->h_plan_lr.p, count * sizeof(double), hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipEventRecord(e->plan_ready, e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->plan_ready, 0));
+    e->plan_count = count;
+    return QE_OK;
 }
 
 int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats) {
@@ -1074,6 +1120,19 @@ int qe_delta_apply_dev(qe_engine* e, const void* dev_entries, int64_t count) {
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_delta_apply<float>, dim3(grid_for(count, 256)), dim3(256), 0, e->stream,
                        (float*)e->q, (const DeltaEntry*)dev_entries, count);
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+int qe_delta_apply_skip_dev(qe_engine* e, const void* dev_entries, int64_t count, int64_t skip_begin,
+                            int64_t skip_end) {
+    if (!e || skip_begin < 0 || skip_end < skip_begin || skip_end > count) return fail(QE_ERR_INVALID, "bad argument");
+    const int64_t live = count - (skip_end - skip_begin);
+    if (live <= 0) return QE_OK;
+    if (e->dtype != QE_F32) return fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_delta_apply_skip<float>, dim3(grid_for(live, 256)), dim3(256), 0, e->stream, (float*)e->q,
+                       (const DeltaEntry*)dev_entries, count, skip_begin, skip_end - skip_begin);
     HIP_TRY(hipGetLastError());
     return QE_OK;
 }

@@ -1488,4 +1488,13 @@ __global__ void k_delta_apply(T* q, const DeltaEntry* e, int64_t count) {
     if (i < count) atomicAdd(q + e[i].cell, (T)e[i].delta);
 }
 
+// the all-gathered logs of every rank, minus this rank's own segment [skip_begin, skip_end)
+template <typename T>
+__global__ void k_delta_apply_skip(T* q, const DeltaEntry* e, int64_t count, int64_t skip_begin, int64_t skip_len) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count - skip_len) return;
+    if (i >= skip_begin) i += skip_len;
+    atomicAdd(q + e[i].cell, (T)e[i].delta);
+}
+
 }  // namespace qe

@@ -33,8 +33,9 @@ import torch.distributed as dist
 
 class DeltaSync:
     def __init__(self, capacity: int, device, apply_fn, attach_fn=None, group=None, overlap: bool = True,
-                 stream=None) -> None:
+                 stream=None, apply_skip_fn=None) -> None:
         self.stream = stream  # torch.cuda.Stream the engine runs on (None on CPU / current stream)
+        self.apply_skip_fn = apply_skip_fn  # (entries, total, skip_begin, skip_end): one-launch form
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -72,8 +73,11 @@ class DeltaSync:
         if work is not None:
             work.wait()  # the current stream now waits for the collective; the host does not block
         g = self.gathered[buf]
-        if count == self.capacity and self.world > 2:
-            # full segments are contiguous: everything before / after my own segment in two launches
+        if count == self.capacity and self.apply_skip_fn is not None:
+            # full segments are contiguous: every rank's records except my own in ONE launch
+            self.apply_skip_fn(g.reshape(-1, 2), count * self.world, count * self.rank, count * (self.rank + 1))
+        elif count == self.capacity and self.world > 2:
+            # everything before / after my own segment in two launches
             if self.rank > 0:
                 self.apply_fn(g[: self.rank].reshape(-1, 2), count * self.rank)
             if self.rank < self.world - 1:
@@ -140,6 +144,10 @@ def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overl
     def attach_fn(log):
         _lib.check(lib.qe_delta_log_attach(algorithm.handle, C.c_void_p(log.data_ptr()), capacity))
 
-    sync = DeltaSync(capacity, dev, apply_fn, attach_fn, group, overlap, stream)
+    def apply_skip_fn(entries, total, skip_begin, skip_end):
+        _lib.check(lib.qe_delta_apply_skip_dev(algorithm.handle, C.c_void_p(entries.data_ptr()), int(total),
+                                               int(skip_begin), int(skip_end)))
+
+    sync = DeltaSync(capacity, dev, apply_fn, attach_fn, group, overlap, stream, apply_skip_fn)
     stream.wait_stream(torch.cuda.current_stream())  # buffer initialisation ran on the current stream
     return sync

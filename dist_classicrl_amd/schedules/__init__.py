@@ -61,9 +61,20 @@ class ExponentialSchedule(BaseSchedule):
         self.set_value(max(self.get_value() * (self.decay_rate**steps), self.min_value))
 
     def advance_values(self, n_updates: int, count: int) -> np.ndarray:
+        v, lo, f = float(self.get_value()), float(self.min_value), float(self.decay_rate**n_updates)
+        if count > 0 and 0.0 <= f <= 1.0 and lo >= 0.0:
+            # The recurrence is a running product until it first falls to the floor and the floor from
+            # then on (lo * f <= lo).  multiply.accumulate performs the same float64 products in the
+            # same order as the loop below, so the values are identical bit for bit.
+            prod = np.multiply.accumulate(np.concatenate(([v], np.full(count, f, dtype=np.float64))))
+            below = np.flatnonzero(prod[1:] <= lo)
+            k = int(below[0]) + 1 if below.size else count + 1  # first step that reads the floor
+            out = prod[:count].copy()
+            out[k:] = lo
+            self.set_value(lo if k <= count else float(prod[count]))
+            return out
         out = np.empty(count, dtype=np.float64)
-        v, lo, f = self.get_value(), self.min_value, self.decay_rate**n_updates
-        for t in range(count):  # sequential on purpose: the clamp makes it non-associative
+        for t in range(count):  # general case (growing or negative schedules), sequential
             out[t] = v
             v = max(v * f, lo)
         self.set_value(v)
@@ -81,13 +92,11 @@ class LinearSchedule(BaseSchedule):
         self.set_value(self.get_value() + steps * self.decay_rate)
 
     def advance_values(self, n_updates: int, count: int) -> np.ndarray:
-        out = np.empty(count, dtype=np.float64)
-        v, inc = self.get_value(), n_updates * self.decay_rate
-        for t in range(count):
-            out[t] = v
-            v = v + inc
-        self.set_value(v)
-        return out
+        v, inc = float(self.get_value()), float(n_updates * self.decay_rate)
+        # add.accumulate performs the same float64 additions in the same order as `update`
+        run = np.add.accumulate(np.concatenate(([v], np.full(count, inc, dtype=np.float64))))
+        self.set_value(float(run[count]))
+        return run[:count].copy()
 
 
 __all__ = ["BaseSchedule", "ConstantSchedule", "ExponentialSchedule", "LinearSchedule"]

@@ -160,6 +160,12 @@ int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, cons
 int qe_rollout_begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
                      int32_t mode, int32_t slot);
 int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats);
+/* Schedule plan: the eps[t] / lr[t] values of a whole training call (same meaning as in qe_rollout),
+ * uploaded once.  Afterwards qe_rollout_begin may be called with eps == NULL and lr == NULL: each
+ * such call consumes the next `steps` values of the plan, so a call chopped into many short rollouts
+ * (replica exchange every 100 steps) pays for one upload instead of one per rollout.  A new plan
+ * replaces the old one; it may only be set while no rollout is in flight. */
+int qe_schedule_plan(qe_engine* e, const double* eps, const double* lr, int64_t count);
 /* qe_evaluate <- BaseRuntime.evaluate_steps / evaluate_episodes (base_runtime.py:293-384): greedy,
  * no learning.  Runs `steps` vector steps. */
 int qe_evaluate(qe_engine* e, qe_env* env, int64_t steps, qe_rollout_stats* stats);
@@ -175,6 +181,10 @@ int qe_delta_log_attach(qe_engine* e, void* dev_buf, int64_t capacity);
 int64_t qe_delta_log_count(qe_engine* e);
 int qe_delta_log_reset(qe_engine* e);
 int qe_delta_apply_dev(qe_engine* e, const void* dev_entries, int64_t count);
+/* Same over an all-gathered buffer: applies entries [0, count) except [skip_begin, skip_end) -- this
+ * rank's own segment, which is already in its table -- in ONE launch. */
+int qe_delta_apply_skip_dev(qe_engine* e, const void* dev_entries, int64_t count, int64_t skip_begin,
+                            int64_t skip_end);
 
 #ifdef __cplusplus
 }

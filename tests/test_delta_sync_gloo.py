@@ -40,7 +40,7 @@ def _apply(q, cells, deltas):
     np.add.at(q.reshape(-1), cells, deltas)
 
 
-def _worker(rank, world, port, out_dir, overlap):
+def _worker(rank, world, port, out_dir, overlap, one_launch=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dist_classicrl_amd.distributed.delta_sync import DeltaSync
@@ -52,14 +52,20 @@ def _worker(rank, world, port, out_dir, overlap):
         e = entries[:count].numpy()
         _apply(run.q, e[:, 0], e[:, 1].view(np.float32))
 
-    cap = S * A
-    sync = DeltaSync(cap, "cpu", apply_fn, overlap=overlap)
+    def apply_skip_fn(entries, total, skip_begin, skip_end):  # the engine's one-launch form
+        e = entries[:total].numpy()
+        keep = np.r_[0:skip_begin, skip_end:total]
+        _apply(run.q, e[keep, 0], e[keep, 1].view(np.float32))
+
+    # one_launch: fixed-size logs like the engine's (slot = step * n + agent), so count == capacity
+    cap = CHUNK * N_PER_RANK if one_launch else S * A
+    sync = DeltaSync(cap, "cpu", apply_fn, overlap=overlap, apply_skip_fn=apply_skip_fn if one_launch else None)
     for k in range(CHUNKS):
         cells, deltas = _run_chunk(run, k)
         # every rank must exchange the same record count: pad with (cell 0, +0.0) no-ops
         cnt = torch.tensor([cells.size])
         dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-        count = int(cnt.item())
+        count = cap if one_launch else int(cnt.item())
         log = sync.log  # the buffer the "engine" writes this chunk's records into
         log.zero_()
         log[:cells.size, 0] = torch.from_numpy(cells)
@@ -72,14 +78,14 @@ def _worker(rank, world, port, out_dir, overlap):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_two_rank_replica_sync_matches_single_process_simulation(tmp_path, overlap):
+@pytest.mark.parametrize(("overlap", "one_launch"), [(False, False), (True, False), (True, True)])
+def test_two_rank_replica_sync_matches_single_process_simulation(tmp_path, overlap, one_launch):
     from oracle import c_oracle
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), overlap, one_launch), nprocs=2, join=True)
     q0, q1 = np.load(tmp_path / "q0.npy"), np.load(tmp_path / "q1.npy")
 
     # single-process simulation of the same protocol: without overlap the other rank's records are

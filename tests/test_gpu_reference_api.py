@@ -330,3 +330,13 @@ def test_delta_log_and_apply_reproduce_a_replica():
         assert np.allclose(qa, qb, rtol=1e-5, atol=1e-6)
         cells = log[:, 0].cpu().numpy()
         assert cells.min() >= 0 and cells.max() < S * A
+        # one-launch form over an all-gathered buffer: three segments, the middle one (own) skipped
+        c = OptimalQLearningBase(S, A, 0.99, seed=0)
+        _lib.check(lib.qe_set_stream(c.handle, stream))
+        junk = torch.full_like(log, 7)  # (cell 7, +1000.0): would wreck the table if it were applied
+        junk[:, 1] = 0x447A0000
+        gathered = torch.cat([log, junk, log]).contiguous()
+        m = steps * n
+        _lib.check(lib.qe_delta_apply_skip_dev(c.handle, C.c_void_p(gathered.data_ptr()), 3 * m, m, 2 * m))
+        torch.cuda.synchronize()
+        assert np.allclose(np.asarray(c.q_table), 2.0 * qa, rtol=2e-5, atol=2e-6)
