@@ -570,6 +570,8 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         const char* sb[6] = {"sb list", "sb hash+stage", "sb cache+ranks", "sb rounds", "sb account", "sb select"};
         for (int k = 0; k < 6; ++k) fprintf(stderr, "  [stamps] %-20s %8.1f ns/step\n", sb[k], seg[8 + k] * 10.0 / sl.steps);
         fprintf(stderr, "  [stamps] slow_body calls %.0f, rounds/call %.2f\n", seg[15], seg[15] > 0 ? seg[14] / seg[15] : 0.0);
+        fprintf(stderr, "  [stamps] busy steps %.0f, with deferred agents %.0f, in-place rounds %.0f, extended time %.1f ns/step\n",
+                seg[16], seg[17], seg[18], seg[19] * 10.0 / sl.steps);
     }
 #endif
     if (fin.error) return fail(QE_ERR_NO_DEVICE, "ordered path gave up (internal error %u)", fin.error);

@@ -1048,8 +1048,14 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
 
         if (busy) {
             // ---- extended step: ordered updates of the deferred agents, then late selections -----
+#ifdef QE_STAMPS
+            const long long ext_t0 = wall_clock64();
+#endif
             __syncthreads();
             const int n_def = (int)lds.n_def;
+#ifdef QE_STAMPS
+            if (tid == 0) { c.vinc[16] += 1.0; if (n_def > 0) c.vinc[17] += 1.0; }
+#endif
             if (n_def > 0) {
                 deferred_total += (unsigned long long)n_def;
                 if (lds.complex_) {
@@ -1080,6 +1086,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
                     if (LC != 1) { pred_s = group_bcast<LC, 0>(pred_s, L); pred_n = group_bcast<LC, 0>(pred_n, L); }
                     int rounds = 0;
                     while (lds.n_rem > 0u && rounds++ <= n_def) {
+#ifdef QE_STAMPS
+                        if (tid == 0) c.vinc[18] += 1.0;
+#endif
                         const bool go = mine && (pred_s < 0 || lds.pending[pred_s] == 0) &&
                                         (pred_n < 0 || lds.pending[pred_n] == 0);
                         __syncthreads();  // everyone has sampled the flags of this round
@@ -1111,6 +1120,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
                 advance_with_draws<T, Env, LC>(c, ev, i, sub, fresh, valid, t + 1, sflags, x, p);
             }
             if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }
+#ifdef QE_STAMPS
+            if (tid == 0) c.vinc[19] += (double)(wall_clock64() - ext_t0);
+#endif
         }
         // ---- bulk flush of the staged episode log (uniform, data-independent decision) ----------
         if (--flush_in == 0 || last) {
