@@ -133,20 +133,35 @@ constexpr int DPP_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
 constexpr int DPP_SHR1 = 0x111;    // row_shr:1
 constexpr int DPP_SHR2 = 0x112;    // row_shr:2
-constexpr bool dpp_width(int LC) { return LC == 2 || LC == 4; }
+constexpr int DPP_SHR4 = 0x114;    // row_shr:4
+constexpr int DPP_SHR8 = 0x118;    // row_shr:8
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane k <-> 7-k inside each 8 lanes
+constexpr int DPP_MIRROR = 0x140;       // lane k <-> 15-k inside each row of 16 lanes
+constexpr bool dpp_width(int LC) { return LC == 2 || LC == 4 || LC == 8 || LC == 16; }
+// Reductions over 8 / 16 lanes pair every lane with its mirror image first (there is no xor-4 / xor-8
+// DPP pattern): after mirror and half-mirror, lane j of a quad holds the combination of lanes
+// {j, 7-j, 8+j, 15-j}, and the two quad steps complete the group.
 
 // value held by lane K of the group (K a compile-time constant)
 template <int LC, int K, typename T>
 __device__ __forceinline__ T group_bcast(T v, int L) {
-    if constexpr (LC == 4) return dpp_mov<K * 0x55>(v);                 // quad_perm:[K,K,K,K]
+    if constexpr (LC == 4) return dpp_mov<(K & 3) * 0x55>(v);           // quad_perm:[K,K,K,K]
     else if constexpr (LC == 2) return dpp_mov<K ? 0xF5 : 0xA0>(v);     // quad_perm:[K,K,2+K,2+K]
     else return __shfl(v, K, LC ? LC : L);
 }
 
 template <int LC = 0, typename T>
 __device__ __forceinline__ T group_max(T v, int L) {
-    if constexpr (LC == 4) {
-        T o = dpp_mov<DPP_XOR2>(v);
+    if constexpr (LC == 16) {
+        const T o = dpp_mov<DPP_MIRROR>(v);
+        v = o > v ? o : v;
+    }
+    if constexpr (LC >= 8 && dpp_width(LC)) {
+        const T o = dpp_mov<DPP_HALF_MIRROR>(v);
+        v = o > v ? o : v;
+    }
+    if constexpr (LC >= 4 && dpp_width(LC)) {
+        const T o = dpp_mov<DPP_XOR2>(v);
         v = o > v ? o : v;
     }
     if constexpr (dpp_width(LC)) {
@@ -171,7 +186,9 @@ __device__ __forceinline__ int group_max_int(int v, int L) {
 template <int LC>
 __device__ __forceinline__ unsigned group_or(unsigned v) {
     static_assert(dpp_width(LC), "DPP widths only");
-    if constexpr (LC == 4) v |= dpp_mov<DPP_XOR2>(v);
+    if constexpr (LC == 16) v |= dpp_mov<DPP_MIRROR>(v);
+    if constexpr (LC >= 8) v |= dpp_mov<DPP_HALF_MIRROR>(v);
+    if constexpr (LC >= 4) v |= dpp_mov<DPP_XOR2>(v);
     return v | dpp_mov<DPP_XOR1>(v);
 }
 template <int LC>
@@ -220,13 +237,25 @@ __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4
     int incl = cnt;
     int total;
     if constexpr (dpp_width(LC)) {
+        // row_shr reaches across the group boundary inside a row of 16 lanes; the `sub >=` guards
+        // discard exactly those values
         int t = dpp_mov<DPP_SHR1>(incl);
         if (sub >= 1) incl += t;
-        if constexpr (LC == 4) {
+        if constexpr (LC >= 4) {
             t = dpp_mov<DPP_SHR2>(incl);
             if (sub >= 2) incl += t;
         }
-        total = group_bcast<LC, LC - 1>(incl, L);
+        if constexpr (LC >= 8) {
+            t = dpp_mov<DPP_SHR4>(incl);
+            if (sub >= 4) incl += t;
+        }
+        if constexpr (LC == 16) {
+            t = dpp_mov<DPP_SHR8>(incl);
+            if (sub >= 8) incl += t;
+        }
+        // the inclusive counts never decrease along the group, so their maximum is the total
+        if constexpr (LC <= 4) total = group_bcast<LC, LC - 1>(incl, L);
+        else total = group_max<LC, int>(incl, L);
     } else {
 #pragma unroll
         for (int off = 1; off < L; off <<= 1) {

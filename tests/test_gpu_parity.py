@@ -242,6 +242,9 @@ def test_rollout_matches_reference_golden(name, path):
         (("hash", 256, 40, 16, False), 60, "f4", "iter"),  # persistent kernel, every step contested
         (("hash", 250, 90, 13, True), 50, "f8", "iter"),
         (("hash", 120, 3000, 32, True), 80, "f4", "vec"),
+        (("hash", 128, 700, 32, False), 60, "f4", "iter"),  # persistent, 8 lanes per row
+        (("hash", 64, 300, 64, True), 60, "f8", "iter"),  # persistent, 16 lanes per row
+        (("hash", 60, 500, 50, False), 70, "f4", "iter"),  # 16 lanes per row, A not a multiple of 4
         (("hash", 500, 100000, 8, False), 100, "f4", "iter"),
         (("grid", 1000, 5), 30, "f4", "iter"),
         (("grid", 500, 5), 40, "f8", "iter"),
