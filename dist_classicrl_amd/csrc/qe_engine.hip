@@ -317,12 +317,12 @@ constexpr int MAX_SAMPLES = 256;
 
 constexpr int GRAPH_STEPS = 50;  // vector steps per captured graph (step-wise / wide paths)
 
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow,
                  int sample = -1) {
     const dim3 grid(grid_for(c.N * c.L, FAST_BLOCK)), block(FAST_BLOCK);
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample], e->stream);
-    hipLaunchKernelGGL((k_step_fast<T, Env>), grid, block, 0, e->stream, c, ev, flags);
+    hipLaunchKernelGGL((k_step_fast<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags);
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
     ++sl.launches;
     if (!slow) return;
@@ -339,24 +339,40 @@ void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& e
                     ++launches;
                 }
                 const bool second = r >= LISTED_RECOMPACT;
-                hipLaunchKernelGGL((k_token_round_list<T, Env>), lgrid, block, 0, e->stream, c, ev, flags, r,
+                hipLaunchKernelGGL((k_token_round_list<T, Env, LC>), lgrid, block, 0, e->stream, c, ev, flags, r,
                                    (const int32_t*)(second ? c.inv_list : c.pend_list), second ? 1 : 0);
             }
-            hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
-            hipLaunchKernelGGL((k_advance_list<T, Env>), lgrid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1,
+            hipLaunchKernelGGL((k_step_slow<T, Env, LC>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
+            hipLaunchKernelGGL((k_advance_list<T, Env, LC>), lgrid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1,
                                (const int32_t*)c.pend_list);
             sl.launches += rounds + launches;
             return;
         }
         for (int r = 0; r < rounds; ++r)
-            hipLaunchKernelGGL((k_token_round<T, Env>), grid, block, 0, e->stream, c, ev, flags, r);
-        hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
-        hipLaunchKernelGGL((k_advance<T, Env>), grid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1);
+            hipLaunchKernelGGL((k_token_round<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags, r);
+        hipLaunchKernelGGL((k_step_slow<T, Env, LC>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
+        hipLaunchKernelGGL((k_advance<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1);
         sl.launches += rounds + 2;
         return;
     }
-    hipLaunchKernelGGL((k_step_slow<T, Env>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
+    hipLaunchKernelGGL((k_step_slow<T, Env, LC>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
     ++sl.launches;
+}
+
+// Lane-group widths of the BASELINE shapes get kernels with compile-time width (DPP lane exchange
+// instead of ds_bpermute); everything else runs the generic build.
+template <typename T, class Env>
+void launch_step_any(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow,
+                     int sample = -1) {
+    if constexpr (std::is_same<Env, HashEnv>::value) {
+        switch (c.L) {
+            case 4: return launch_step<T, Env, 4>(e, sl, c, ev, flags, slow, sample);
+            case 8: return launch_step<T, Env, 8>(e, sl, c, ev, flags, slow, sample);
+            case 16: return launch_step<T, Env, 16>(e, sl, c, ev, flags, slow, sample);
+            default: break;
+        }
+    }
+    launch_step<T, Env, 0>(e, sl, c, ev, flags, slow, sample);
 }
 
 // Enqueue one rollout (no host synchronisation): schedules, control block, kernels, events.
@@ -432,7 +448,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         ++sl.launches;
     } else if (learn) {
         const int base = FLAG_ACCOUNT;
-        launch_step<T, Env>(e, sl, c, ev, base | FLAG_SELECT, false);  // select(0), env.step(0)
+        launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_SELECT, false);  // select(0), env.step(0)
         while ((int)sl.sample_ev.size() < 2 * MAX_SAMPLES) {
             hipEvent_t evn;
             HIP_TRY(hipEventCreate(&evn));
@@ -447,14 +463,14 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         const int64_t eager_head = std::min<int64_t>(middle, 32);
         for (; done < eager_head; ++done) {
             const int sample = sl.n_samples < MAX_SAMPLES ? sl.n_samples++ : -1;
-            launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, sample);
+            launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, sample);
         }
         if (e->opt_graph && middle - done >= 2 * GRAPH_STEPS) {
             if (sl.graph_exec) { (void)hipGraphExecDestroy(sl.graph_exec); sl.graph_exec = nullptr; }
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             const int64_t before = sl.launches;
-            for (int k = 0; k < GRAPH_STEPS; ++k) launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true);
+            for (int k = 0; k < GRAPH_STEPS; ++k) launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true);
             const int64_t per_replay = sl.launches - before;
             sl.launches = before;
             HIP_TRY(hipStreamEndCapture(e->stream, &graph));
@@ -466,8 +482,8 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                 sl.launches += per_replay;
             }
         }
-        for (; done < middle; ++done) launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true);
-        launch_step<T, Env>(e, sl, c, ev, base | FLAG_LEARN, true);  // learn(steps-1)
+        for (; done < middle; ++done) launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true);
+        launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_LEARN, true);  // learn(steps-1)
     } else {
         // greedy evaluation: no table writes, hence no contention and no ordered path
         hipLaunchKernelGGL((k_eval<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK), 0,

@@ -222,7 +222,7 @@ __device__ __forceinline__ void advance_agent(const Ctx<T>& c, const EnvCtx& ev,
 }
 
 // -------------------------------------------------------------------------------------------------
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, int flags) {
     const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
     const int64_t i = gl >> c.lshift;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
         const int32_t a = c.a[i];
         const float r = c.r[i];
         const bool term = c.term[i] != 0;
-        const T m = row_max_valid(row, valid, c.L);
+        const T m = row_max_valid<LC>(row, valid, c.L);
         if (sub == 0) {
             c.stamps[2 * (int64_t)s + par] = 0ull;
             if (n != s) c.stamps[2 * (int64_t)n + par] = 0ull;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
         }
         t1 = t + 1;
     }
-    if (flags & FLAG_SELECT) advance_agent<T, Env>(c, ev, i, sub, n, row, valid, t1, flags);
+    if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t1, flags);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -758,7 +758,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
 
 using SlowLds = SlowLdsT<SLOW_CAP, SLOW_CACHE_BYTES>;
 
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, int flags) {
     __shared__ SlowLds lds;
     const long long t = c.ctrl->t_local;
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, i
     if (t == 0 && threadIdx.x == 0 && c.vinc) for (int k = 0; k < 24; ++k) c.vinc[k] = 0.0;
     __syncthreads();
 #endif
-    if (M > 0 && (flags & FLAG_LEARN)) slow_body<T, Env, SLOW_CAP, SLOW_CACHE_BYTES>(c, ev, flags, t, M, lds);
+    if (M > 0 && (flags & FLAG_LEARN)) slow_body<T, Env, SLOW_CAP, SLOW_CACHE_BYTES, LC>(c, ev, flags, t, M, lds);
     __syncthreads();
     if (threadIdx.x == 0) {
         c.ctrl->involved_total += (unsigned long long)M;
@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
 // otherwise it posts itself for the next round.  No two agents that update in the same round share a
 // row.  After a fixed number of rounds the single-workgroup slow_body finishes whatever is left
 // (long chains), and k_advance performs the postponed selections once every update of the step is in.
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __device__ __forceinline__ void token_round_agent(const Ctx<T>& c, const EnvCtx& ev, int flags, int round,
                                                   int64_t i, int sub, long long t) {
     const int32_t s = c.s[i], a = c.a[i], n = c.n[i];
@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void token_round_agent(const Ctx<T>& c, const EnvCtx&
         T m = 0;
         if (!term) {
             const Row4<T> row = load_row4(c.q, n, c.ld, sub);
-            m = row_max_valid(row, Env::valid4(ev, i, n, sub), c.L);
+            m = row_max_valid<LC>(row, Env::valid4(ev, i, n, sub), c.L);
         }
         if (sub == 0) {
             const int64_t cell = (int64_t)s * c.ld + a;
@@ -1199,14 +1199,14 @@ __device__ __forceinline__ void token_round_agent(const Ctx<T>& c, const EnvCtx&
     }
 }
 
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __global__ __launch_bounds__(FAST_BLOCK) void k_token_round(Ctx<T> c, EnvCtx ev, int flags, int round) {
     const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
     const int64_t i = gl >> c.lshift;
     const int sub = (int)(gl & (c.L - 1));
     if (i >= c.N) return;
     if (!((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u)) return;  // not pending (whole lane group leaves)
-    token_round_agent<T, Env>(c, ev, flags, round, i, sub, c.ctrl->t_local);
+    token_round_agent<T, Env, LC>(c, ev, flags, round, i, sub, c.ctrl->t_local);
 }
 
 // At large N a round that scans every agent costs more than the work of the few that are still
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_compact(Ctx<T> c, const uint32_t
     }
 }
 
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __global__ __launch_bounds__(FAST_BLOCK) void k_token_round_list(Ctx<T> c, EnvCtx ev, int flags, int round,
                                                                  const int32_t* list, int which) {
     const int count = (int)c.ctrl->pend_count[which];
@@ -1247,13 +1247,13 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_token_round_list(Ctx<T> c, EnvCt
     for (int p = (int)blockIdx.x * gpb + (int)(threadIdx.x >> c.lshift); p < count; p += (int)gridDim.x * gpb) {
         const int64_t i = list[p];
         if (!((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u)) continue;
-        token_round_agent<T, Env>(c, ev, flags, round, i, sub, t);
+        token_round_agent<T, Env, LC>(c, ev, flags, round, i, sub, t);
     }
 }
 
 // Postponed selections of wide mode: every agent that was involved in step t selects its action of
 // step t+1 only now, when all updates of step t are in the table (also clears its stamps).
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __device__ __forceinline__ void advance_postponed(const Ctx<T>& c, const EnvCtx& ev, int flags, int64_t i, int sub,
                                                   long long t) {
     const int32_t s = c.s[i], n = c.n[i];
@@ -1265,30 +1265,30 @@ __device__ __forceinline__ void advance_postponed(const Ctx<T>& c, const EnvCtx&
     }
     if (flags & FLAG_SELECT) {
         Row4<T> row = load_row4(c.q, n, c.ld, sub);
-        advance_agent<T, Env>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
+        advance_agent<T, Env, LC>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
     }
 }
 
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __global__ __launch_bounds__(FAST_BLOCK) void k_advance(Ctx<T> c, EnvCtx ev, int flags) {
     const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
     const int64_t i = gl >> c.lshift;
     const int sub = (int)(gl & (c.L - 1));
     if (i >= c.N) return;
     if (!((c.adv_bitmap[i >> 5] >> (i & 31)) & 1u)) return;
-    advance_postponed<T, Env>(c, ev, flags, i, sub, c.ctrl->t_local - ((flags & FLAG_T_MINUS_1) ? 1 : 0));
+    advance_postponed<T, Env, LC>(c, ev, flags, i, sub, c.ctrl->t_local - ((flags & FLAG_T_MINUS_1) ? 1 : 0));
 }
 
 // Listed variant: the first pending list of the step holds exactly the agents whose selection was
 // postponed.  The last block to leave resets the list counters for the next step.
-template <typename T, class Env>
+template <typename T, class Env, int LC = 0>
 __global__ __launch_bounds__(FAST_BLOCK) void k_advance_list(Ctx<T> c, EnvCtx ev, int flags, const int32_t* list) {
     const int count = (int)c.ctrl->pend_count[0];
     const int gpb = FAST_BLOCK >> c.lshift;
     const int sub = (int)(threadIdx.x & (c.L - 1));
     const long long t = c.ctrl->t_local - ((flags & FLAG_T_MINUS_1) ? 1 : 0);
     for (int p = (int)blockIdx.x * gpb + (int)(threadIdx.x >> c.lshift); p < count; p += (int)gridDim.x * gpb)
-        advance_postponed<T, Env>(c, ev, flags, list[p], sub, t);
+        advance_postponed<T, Env, LC>(c, ev, flags, list[p], sub, t);
 }
 
 // -------------------------------------------------------------------------------------------------
