@@ -306,8 +306,10 @@ struct Td;
 template <>
 struct Td<float> {
     static __device__ __forceinline__ double vec_inc(float q, float r, float m, bool term, const Hyper& h) {
+        // learn_vec multiplies by (1 - terminated) instead of selecting (q_learning_optimal.py:889): a
+        // terminated transition whose next row has an infinite maximum yields inf * 0 = NaN there too
         const float t32 = h.gamma32 * m;
-        const double t = term ? 0.0 : (double)t32;
+        const double t = (double)t32 * (term ? 0.0 : 1.0);
         const double y = (double)r + t;
         const double d = y - (double)q;
         return h.lr * d;
@@ -333,15 +335,17 @@ struct Td<float> {
 
 template <>
 struct Td<double> {
-    static __device__ __forceinline__ double delta(double q, float r, double m, bool term, const Hyper& h) {
-        const double t = term ? 0.0 : h.gamma * m;
+    // vec = learn_vec arithmetic: gamma * max * (1 - terminated), see Td<float>::vec_inc
+    static __device__ __forceinline__ double delta(double q, float r, double m, bool term, const Hyper& h,
+                                                   bool vec = false) {
+        const double t = vec ? (h.gamma * m) * (term ? 0.0 : 1.0) : (term ? 0.0 : h.gamma * m);
         const double y = (double)r + t;
         const double d = y - q;
         return h.lr * d;
     }
     static __device__ __forceinline__ double apply(double q, float r, double m, bool term,
-                                                   const Hyper& h, int /*mode*/, double* inc) {
-        const double u = delta(q, r, m, term, h);
+                                                   const Hyper& h, int mode, double* inc) {
+        const double u = delta(q, r, m, term, h, mode == 1);
         *inc = u;
         return q + u;
     }

@@ -590,6 +590,7 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
                 seg[16], seg[17], seg[18], seg[19] * 10.0 / sl.steps);
     }
 #endif
+    if (fin.error == ERR_EMPTY_CHOICE) return fail(QE_ERR_INDEX, "Cannot choose from an empty sequence");
     if (fin.error) return fail(QE_ERR_NO_DEVICE, "ordered path gave up (internal error %u)", fin.error);
     return QE_OK;
 }

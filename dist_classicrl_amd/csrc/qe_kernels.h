@@ -38,6 +38,7 @@ constexpr int FLAG_ACCOUNT = 16;         // episode-return bookkeeping (rollouts
 constexpr int FLAG_NO_STAMPS = 32;       // persistent kernel: contention is tracked in LDS instead
 constexpr int FLAG_T_MINUS_1 = 64;       // the step counter has already been advanced (k_advance)
 constexpr uint32_t TOK_INF = 0xFFFFFFFFu;
+constexpr unsigned ERR_EMPTY_CHOICE = 3u;  // Ctrl::error: a fused selection found no selectable action
 
 struct Ctrl {
     long long t_local;                   // vector step inside the current rollout call
@@ -182,7 +183,14 @@ __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx
                                                    int flags, const U4& x, Pending<T>& p) {
     const bool explore = !(flags & FLAG_DETERMINISTIC) && (unsigned long long)x.x < c.thr[t1];
     T picked;
-    const int act = select_action<LC>(row, valid, sub, c.L, explore, x.y, x.z, &picked);
+    int act = select_action<LC>(row, valid, sub, c.L, explore, x.y, x.z, &picked);
+    if (act < 0) {
+        // No selectable action: every action masked, or the row maximum is NaN (diverged training), where
+        // the reference's random.choice raises IndexError (q_learning_optimal.py:470,563).  Reported
+        // through the control block; action 0 keeps the rest of the rollout inside the table.
+        if (sub == 0) c.ctrl->error = ERR_EMPTY_CHOICE;
+        act = 0;
+    }
     const int32_t n = p.n;
     const Transition tr = Env::step(ev, i, n, p.aux, act, c.step0 + (unsigned long long)t1);
     if (sub == 0) {
@@ -455,8 +463,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
     if (c.mode == 1) {
         // ---- VEC (learn_vec / np.add.at, q_learning_optimal.py:235-250,889-891): every involved
         // agent forms its increment from the pre-step table; increments that collide on a cell
-        // are then accumulated in agent order by the first of them (exactly np.add.at), or with
-        // atomicAdd when there are too many involved agents to pair them up in LDS.
+        // are then accumulated in agent order by the first of them (exactly np.add.at).
         double* inc = c.vinc;
         uint32_t* cells = reinterpret_cast<uint32_t*>(lds.t_next);
         for (int p0 = 0; p0 < M; p0 += ngrp) {  // pass A: reads
@@ -472,7 +479,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                     const Hyper h = make_hyper(c, c.lr[t]);
                     double u;
                     if constexpr (sizeof(T) == 4) u = Td<float>::vec_inc(q0, g.r, m, g.term, h);
-                    else u = Td<double>::delta(q0, g.r, m, g.term, h);
+                    else u = Td<double>::delta(q0, g.r, m, g.term, h, true);
                     inc[i] = u;
                     if (pos < 2 * CAP) cells[pos] = (uint32_t)cell;
                     log_delta(c, t, i, cell, (T)u);
@@ -480,21 +487,29 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
             }
         }
         __syncthreads();
-        if (M <= 2 * CAP) {
-            for (int pos = tid; pos < M; pos += BS) {  // pass B: ordered accumulate
+        // pass B: per cell, the increments are added in agent order, each addition in float64 and rounded
+        // into the table dtype (exactly np.add.at).  The first involved agent of a cell ("leader") does it
+        // for all of them.  More involved agents than LDS holds are taken in index-ordered batches: a
+        // later batch continues from the value the earlier ones left in the table.
+        for (int base = 0; base < M; base += 2 * CAP) {
+            const int Mb = min(2 * CAP, M - base);
+            if (base) {
+                __syncthreads();
+                for (int pos = tid; pos < Mb; pos += BS) {
+                    const int64_t i = c.inv_list[base + pos];
+                    cells[pos] = (uint32_t)((int64_t)load_live(c.s + i) * c.ld + load_live(c.a + i));
+                }
+                __syncthreads();
+            }
+            for (int pos = tid; pos < Mb; pos += BS) {
                 const uint32_t cell = cells[pos];
                 bool leader = true;
                 for (int j = 0; j < pos && leader; ++j) leader = cells[j] != cell;
                 if (!leader) continue;
-                T q = c.q[cell];
-                for (int j = pos; j < M; ++j)
-                    if (cells[j] == cell) q = (T)((double)q + inc[c.inv_list[j]]);
-                c.q[cell] = q;
-            }
-        } else {
-            for (int pos = tid; pos < M; pos += BS) {  // pass B: scatter-add
-                const int64_t i = c.inv_list[pos];
-                atomicAdd(c.q + (int64_t)c.s[i] * c.ld + c.a[i], (T)inc[i]);
+                T q = load_live(c.q + cell);
+                for (int j = pos; j < Mb; ++j)
+                    if (cells[j] == cell) q = (T)((double)q + inc[c.inv_list[base + j]]);
+                store_live(c.q + cell, q);
             }
         }
     } else for (int base = 0; base < M_all; base += CAP) {
@@ -879,6 +894,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
         c.ctrl->error = 0u;  // this launch owns the control block: no host-side memset in front of it
         c.ctrl->inv_count = 0u;
     }
+    __syncthreads();  // the control block is initialised before any wave may report through it
     {   // select(0), env.step(0)
         const Row4<T> row = load_row4(c.q, p.n, c.ld, sub);
         if (active) advance_regs<T, Env, LC>(c, ev, i, sub, row, Env::valid4(ev, i, p.n, sub), 0, sflags, p);
@@ -1402,7 +1418,7 @@ __global__ __launch_bounds__(64) void k_learn_large(Ctx<T> c, EnvCtx ev, double 
             if (lane == 0) {
                 const T q0 = c.q[(int64_t)c.s[i] * c.ld + c.a[i]];
                 if constexpr (sizeof(T) == 4) inc[i] = Td<float>::vec_inc(q0, c.r[i], m, c.term[i] != 0, h);
-                else inc[i] = Td<double>::delta(q0, c.r[i], m, c.term[i] != 0, h);
+                else inc[i] = Td<double>::delta(q0, c.r[i], m, c.term[i] != 0, h, true);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

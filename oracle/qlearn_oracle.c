@@ -115,12 +115,13 @@ static void td_iter(const oc_cfg* c, void* q, int64_t cell, float r, double m, i
     }
 }
 static double td_vec_inc(const oc_cfg* c, const void* q, int64_t cell, float r, double m, int term, double lr) {
+    /* learn_vec multiplies by (1 - terminated) (q_learning_optimal.py:889): inf * 0 = NaN, like NumPy */
     if (c->dtype) {
-        const double t = term ? 0.0 : c->gamma * m;
+        const double t = (c->gamma * m) * (term ? 0.0 : 1.0);
         return lr * (((double)r + t) - ((const double*)q)[cell]);
     }
     const float t32 = (float)c->gamma * (float)m;
-    const double t = term ? 0.0 : (double)t32;
+    const double t = (double)t32 * (term ? 0.0 : 1.0);
     return lr * (((double)r + t) - (double)((const float*)q)[cell]);
 }
 

@@ -119,12 +119,7 @@ def test_learn_matches_oracle_on_extreme_shapes(S, A, n, masked, dt, fn):
     ref.q_table = q0.copy()
     getattr(algo, fn)(s, a, r, s2, term, 0.05, masks)
     getattr(ref, fn)(s, a, r, s2, term, 0.05, masks)
-    if fn == "learn_vec" and n > 2048:  # collisions resolved with atomicAdd: order not fixed (see next test)
-        per_cell = np.bincount(s.astype(np.int64) * A + a, minlength=S * A).reshape(S, A)
-        tol = (1e-6 if dt == "f4" else 1e-14) * np.maximum(1, per_cell) * np.maximum(1, np.abs(ref.q_table))
-        assert np.all(np.abs(np.asarray(algo.q_table) - ref.q_table) <= tol)
-    else:
-        assert np.array_equal(np.asarray(algo.q_table), ref.q_table)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q_table)
 
 
 def test_empty_batches_are_no_ops():
@@ -142,10 +137,10 @@ def test_empty_batches_are_no_ops():
     assert np.array_equal(np.asarray(algo.q_table), np.arange(40, dtype=np.float32).reshape(10, 4))
 
 
-def test_learn_vec_many_collisions_atomic_path():
-    """> 4096 transitions on shared rows: colliding increments go through atomicAdd, whose order is
-    not fixed.  Tolerance 1e-6 relative per accumulated increment (north star, fp32); cells hit by a
-    single transition stay bit-exact."""
+def test_learn_vec_many_collisions_stay_exact():
+    """20 000 transitions on 800 cells: far more colliding increments than the LDS structures of the ordered
+    path hold, so they are accumulated in index-ordered batches -- still exactly np.add.at's order and
+    rounding (float64 add, rounded into the table dtype), hence bit-exact."""
     from oracle.qlearn_oracle import OracleQLearning
 
     Algo = _product()[0]
@@ -161,9 +156,7 @@ def test_learn_vec_many_collisions_atomic_path():
     ref = OracleQLearning(S, A, 0.9, dtype=np.float32)
     ref.q_table = q0.copy()
     ref.learn_vec(s, a, r, s2, term, 0.01)
-    got = np.asarray(algo.q_table)
-    per_cell = np.bincount(s.astype(np.int64) * A + a, minlength=S * A).reshape(S, A)
-    assert np.all(np.abs(got - ref.q_table) <= 1e-6 * np.maximum(1, per_cell) * np.maximum(1, np.abs(ref.q_table)))
+    assert np.array_equal(np.asarray(algo.q_table), ref.q_table)
 
 
 # ------------------------------------------------------------------------------- closed loop
@@ -242,6 +235,9 @@ def test_rollout_matches_reference_golden(name, path):
         (("hash", 256, 40, 16, False), 60, "f4", "iter"),  # persistent kernel, every step contested
         (("hash", 250, 90, 13, True), 50, "f8", "iter"),
         (("hash", 120, 3000, 32, True), 80, "f4", "vec"),
+        (("hash", 6000, 100000, 12, True), 12, "f4", "vec"),  # > 2048 involved agents in learn_vec: batched, exact
+        (("hash", 2500, 40, 16, False), 20, "f4", "vec"),
+        (("hash", 4096, 2000, 9, True), 16, "f8", "vec"),
         (("hash", 128, 700, 32, False), 60, "f4", "iter"),  # persistent, 8 lanes per row
         (("hash", 64, 300, 64, True), 60, "f8", "iter"),  # persistent, 16 lanes per row
         (("hash", 60, 500, 50, False), 70, "f4", "iter"),  # 16 lanes per row, A not a multiple of 4
@@ -267,6 +263,29 @@ def test_rollout_matches_oracle_seeded(spec, steps, dt, mode, path):
     assert np.array_equal(got["history"], want["history"])
     assert np.array_equal(got["final_obs"], want["final_obs"])
     assert np.array_equal(got["agent_rewards"], want["agent_rewards"])
+
+
+@pytest.mark.parametrize("path", ["stepwise", "persistent", "wide"])
+def test_rollout_without_selectable_action_raises_like_the_reference(path):
+    """A NaN row maximum leaves `np.where(row == max)` empty and the reference's `random.choice` raises
+    IndexError (q_learning_optimal.py:563); the fused rollout reports the same instead of writing outside
+    the table."""
+    Algo, Runtime, envs, sch = _product()
+    n, S, A = (300, 50, 8) if path == "persistent" else (2100, 50, 8)
+    algo = Algo(S, A, 0.99, seed=0)
+    algo.q_table = np.full((S, A), np.nan, dtype=np.float32)
+    algo.set_rollout_path(path)
+    rt = Runtime(algo, sch.ConstantSchedule(0.1), sch.ConstantSchedule(0.1))
+    with pytest.raises(IndexError, match="empty sequence"):
+        rt.run_steps(5, envs.HashTabularEnv(n, S, A, seed=1), None)
+    # the reference's mechanism on such a row (choose_actions_vec, q_learning_optimal.py:548-563)
+    import random
+
+    row = np.full(A, np.nan, dtype=np.float32)
+    candidates = np.where(row == np.max(row))[0]
+    assert candidates.size == 0
+    with pytest.raises(IndexError):
+        random.Random(0).choice(candidates)
 
 
 def test_rollout_resume_equals_one_shot():

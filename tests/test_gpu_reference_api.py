@@ -295,6 +295,31 @@ def test_train_contract():
     assert val_rewards == [10.0, 10.0] and env2 is env and "rewards" in sd
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_terminated_transition_with_infinite_next_row(dt):
+    """`learn_vec` multiplies the bootstrap term by (1 - terminated) (q_learning_optimal.py:889), so an
+    infinite next-row maximum turns a TERMINATED transition into NaN (inf * 0); `learn` selects 0 for
+    terminated transitions (:759) and stays finite.  Both quirks are reproduced."""
+    from oracle.qlearn_oracle import OracleQLearning
+
+    Q = _classes()[0]
+    q0 = np.zeros((3, 2), dtype=dt)
+    q0[2] = [np.inf, 1.0]
+    s, a = np.array([0, 1], dtype=np.int32), np.array([1, 0], dtype=np.int32)
+    r, s2 = np.array([1.0, 2.0], dtype=np.float32), np.array([2, 2], dtype=np.int32)
+    term = np.array([True, False])
+    for fn in ("learn", "learn_vec"):
+        algo, ref = Q(3, 2, 0.9, seed=0, dtype=dt), OracleQLearning(3, 2, 0.9, dtype=np.dtype(dt))
+        algo.q_table = q0
+        ref.q_table = q0.copy()
+        with np.errstate(invalid="ignore"):
+            getattr(ref, fn)(s, a, r, s2, term, 0.5)
+        getattr(algo, fn)(s, a, r, s2, term, 0.5)
+        got = np.asarray(algo.q_table)
+        assert np.array_equal(got, ref.q_table, equal_nan=True)
+        assert np.isnan(got[0, 1]) == (fn == "learn_vec") and np.isinf(got[1, 0])
+
+
 # ----------------------------------------------------------------------------- replica sync on device
 def test_delta_log_and_apply_reproduce_a_replica():
     """Multi-GPU building blocks on one GPU: engine A learns with the delta log attached (buffer and
