@@ -49,7 +49,8 @@ enum qe_dtype { QE_F32 = 0, QE_F64 = 1 };
  *   QE_LEARN_ITER : algorithms/base_algorithms/q_learning_optimal.py:770-817 (learn_iter, what
  *                   `learn` :893-934 dispatches to): strictly sequential over agents.
  *   QE_LEARN_VEC  : :819-891 (learn_vec / _learn_vec + add_q_values :235-250): all reads precede
- *                   all writes, colliding updates accumulate (atomicAdd on device). */
+ *                   all writes, colliding updates accumulate in agent order, each addition in float64 rounded into
+ *                   the table dtype -- np.add.at exactly, at any number of collisions. */
 enum qe_learn_mode { QE_LEARN_ITER = 0, QE_LEARN_VEC = 1 };
 
 enum qe_env_kind {
