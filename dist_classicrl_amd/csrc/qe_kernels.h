@@ -638,13 +638,22 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                 if (sub == 0) { lds.a_m[pos] = (double)m_mine; lds.a_mready[pos] = 1; }
             }
             barrier_lds();
-            while (lds.remaining > 0 && rounds++ <= M) {
+            // the readiness words of a round are fetched together (independent LDS loads, one latency)
+            // and combined without short-circuit evaluation
+            const int prev_i = prev < 0 ? (pos < M ? pos : 0) : prev, sn_i = sn < 0 ? (ss < 0 ? 0 : ss) : sn;
+            const int ss_i = ss < 0 ? 0 : ss, pos_i = pos < M ? pos : 0;
+            for (;;) {
+                const int rem = lds.remaining;
+                const int d_ss = lds.h_done[ss_i], st_prev = lds.a_state[prev_i], d_sn = lds.h_done[sn_i];
+                // own flag: an LDS read issued AFTER the predecessor's (LDS serves a wave's accesses in
+                // order): a run publishes its members last-to-first, so whoever sees its predecessor
+                // finished also sees whether it was swept up itself.
+                asm volatile("" ::: "memory");  // keep the compiler from hoisting the next load above these
+                const int st_me = lds.a_state[pos_i];
+                if (rem <= 0 || rounds++ > M) break;
                 if (waiting) {
-                    bool go = (lds.h_done[ss] & 0xFFFF) == rs && (prev < 0 || lds.a_state[prev] == 1) &&
-                              (sn < 0 || (lds.h_done[sn] >> 16) == rn);
-                    // Read AFTER the predecessor's flag: a run publishes its members last-to-first, so
-                    // whoever sees its predecessor finished also sees whether it was swept up itself.
-                    if (lds.a_state[pos] == 1) { waiting = false; go = false; }
+                    bool go = ((d_ss & 0xFFFF) == rs) & ((prev < 0) | (st_prev == 1)) & ((sn < 0) | ((d_sn >> 16) == rn));
+                    if (st_me == 1) { waiting = false; go = false; }
                     if (go) {
                         T m = m_mine;
                         if (!m_known && !term_ag) {  // every earlier writer of row n has finished by now
@@ -661,7 +670,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                         // so the successors' own lane groups cannot start meanwhile (no claiming needed).
                         T* cell = cache + (int64_t)is * c.ld + a_act;
                         T q_run = *cell;
-                        const int done_readers = lds.h_done[ss] & 0xFFFF;
+                        const int done_readers = d_ss & 0xFFFF;  // (a stale, lower count only ends a run early)
                         int cur = pos, cur_sn = sn, n_run = 0;
                         int64_t cur_ag = ag;
                         float cur_r = r_ag;

@@ -17,9 +17,15 @@ def run(n, S, A, eps, steps, path="auto", masked=False, mode="iter"):
         _lib.check(_lib.load().qe_set_option(algo.handle, 3, int(os.environ["QE_LISTED_MIN"])))
     if os.environ.get("QE_ROUNDS"):
         _lib.check(_lib.load().qe_set_option(algo.handle, 2, int(os.environ["QE_ROUNDS"])))
-    env = HashTabularEnv(n, S, A, seed=1, masked=masked)
+    if os.environ.get("QE_TTT"):
+        from dist_classicrl_amd.environments import TicTacToeEnv
+        algo = OptimalQLearningBase(19683, 9, 0.99, seed=0)
+        env = TicTacToeEnv(n, seed=1)
+    else:
+        env = HashTabularEnv(n, S, A, seed=1, masked=masked)
     e = ConstantSchedule(eps) if eps is not None else ExponentialSchedule(1.0, 0.01, 0.995)
-    rt = GpuRolloutQLearning(algo, ConstantSchedule(0.1), e, learn_mode=mode)
+    lr = ExponentialSchedule(0.1, 1e-5, 0.995) if os.environ.get("QE_BENCH_LR") else ConstantSchedule(0.1)
+    rt = GpuRolloutQLearning(algo, lr, e, learn_mode=mode)
     _, _, _, sd = rt.run_steps(steps // 4 + 1, env, None)
     t0 = time.perf_counter()
     _, h, _, sd = rt.run_steps(steps, env, sd)
