@@ -656,7 +656,12 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     // tuning overrides for experiments (same meaning as the qe_set_option knobs; results never change)
     if (const char* v = getenv("QE_TOKEN_ROUNDS")) e->opt_rounds = std::max(0, std::min(MAX_TOKEN_ROUNDS, atoi(v)));
     if (const char* v = getenv("QE_LISTED_MIN_AGENTS")) e->listed_min = std::max(1, atoi(v));
-    if (const char* v = getenv("QE_USE_GRAPH")) e->opt_graph = atoi(v) != 0;  // rocprofv3 crashes on graph replay
+    // rocprofv3 (ROCm 7.2) segfaults when a captured graph is replayed under --kernel-trace: launch
+    // eagerly when its tool library is preloaded (kernel durations are the same either way)
+    for (const char* var : {"ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "HSA_TOOLS_LIB"})
+        if (const char* v = getenv(var))
+            if (strstr(v, "rocprofiler") || strstr(v, "rocprof")) e->opt_graph = 0;
+    if (const char* v = getenv("QE_USE_GRAPH")) e->opt_graph = atoi(v) != 0;
     const size_t bytes = (size_t)S * e->ld * e->esize();
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
