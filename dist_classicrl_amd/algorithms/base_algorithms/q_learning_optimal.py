@@ -191,7 +191,7 @@ class OptimalQLearningBase:
         np.save(filename, np.asarray(self.q_table))
 
     # ------------------------------------------------------------------ selection (:263-726)
-    def _select(self, states, exploration_rate, deterministic, action_masks):
+    def _select(self, states, exploration_rate, deterministic, action_masks, numpy_variant=False):
         states = _lib.as_i32(states).ravel()
         n = states.size
         masks = None
@@ -203,7 +203,8 @@ class OptimalQLearningBase:
         out = np.empty(n, dtype=np.int32)
         _lib.check(self._lib.qe_choose_actions(
             self._h, _lib.ptr(states, C.c_int32), n, _lib.ptr(masks, C.c_uint8),
-            float(exploration_rate), 1 if deterministic else 0, _lib.ptr(out, C.c_int32)))
+            float(exploration_rate), (1 if deterministic else 0) | (2 if numpy_variant else 0),
+            _lib.ptr(out, C.c_int32)))
         return out
 
     def _list_variant(self, n, deterministic, masked):
@@ -216,8 +217,9 @@ class OptimalQLearningBase:
         return self.action_size <= ACTION_MASKS_NO_DETERMINISTIC_MAX_ACTION_SIZE_ITER
 
     def choose_actions(self, states, exploration_rate, *, deterministic=False, action_masks=None):
-        out = self._select(states, exploration_rate, deterministic, action_masks)
-        if (out < 0).any() and not self._list_variant(out.size, deterministic, action_masks is not None):
+        numpy_variant = not self._list_variant(np.size(states), deterministic, action_masks is not None)
+        out = self._select(states, exploration_rate, deterministic, action_masks, numpy_variant)
+        if numpy_variant and (out < 0).any():
             msg = "Cannot choose from an empty sequence"
             raise IndexError(msg)
         return out
@@ -226,13 +228,13 @@ class OptimalQLearningBase:
         return self._select(states, exploration_rate, deterministic, action_masks)
 
     def choose_actions_vec_iter(self, states, exploration_rate, *, deterministic=False, action_masks=None):
-        return self._raise_on_empty(self._select(states, exploration_rate, deterministic, action_masks))
+        return self._raise_on_empty(self._select(states, exploration_rate, deterministic, action_masks, True))
 
     def choose_actions_vec(self, states, exploration_rate, *, deterministic=False):
         return self._raise_on_empty(self._select(states, exploration_rate, deterministic, None))
 
     def choose_masked_actions_vec(self, states, action_masks, exploration_rate, *, deterministic=False):
-        return self._raise_on_empty(self._select(states, exploration_rate, deterministic, action_masks))
+        return self._raise_on_empty(self._select(states, exploration_rate, deterministic, action_masks, True))
 
     @staticmethod
     def _raise_on_empty(out):
@@ -256,7 +258,7 @@ class OptimalQLearningBase:
     def choose_masked_action_vec(self, state, action_mask, exploration_rate, *, deterministic=False):
         mask = np.asarray(list(action_mask))
         assert mask.size == self.action_size, "Action mask should have the same size as the action space."
-        return int(self._raise_on_empty(self._select([state], exploration_rate, deterministic, mask[None, :]))[0])
+        return int(self._raise_on_empty(self._select([state], exploration_rate, deterministic, mask[None, :], True))[0])
 
     # ------------------------------------------------------------------ learning (:728-934)
     def _learn(self, states, actions, rewards, next_states, terminated, lr, next_action_masks, mode):

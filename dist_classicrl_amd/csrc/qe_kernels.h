@@ -1361,9 +1361,12 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_select(Ctx<T> c, EnvCtx ev, cons
     const uint32_t valid = HostEnv::valid4(ev, i, s, sub);
     const U4 x = philox4x32_10(c.agent_offset + (uint32_t)i, (uint32_t)c.step0,
                                (uint32_t)(c.step0 >> 32), STREAM_POLICY, c.seed_lo, c.seed_hi);
-    const bool explore = !deterministic && (unsigned long long)x.x < thr;
+    const bool explore = !(deterministic & 1) && (unsigned long long)x.x < thr;
     T picked;
-    const int act = select_action(row, valid, sub, c.L, explore, x.y, x.z, &picked);
+    int act = select_action(row, valid, sub, c.L, explore, x.y, x.z, &picked);
+    // NumPy variants of the reference, agent without a valid action: where(mask, Q, -inf) is all -inf, so
+    // every action ties at the maximum and the greedy pick is uniform over ALL actions (:497-503, :618-628)
+    if (act < 0 && (deterministic & 2) && ev.masked && !explore) act = (int)mulhi32(x.z, (uint32_t)c.A);
     if (sub == 0) out[i] = act;
 }
 
@@ -1381,7 +1384,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_select_large(Ctx<T> c, EnvCtx ev
     auto ok = [&](int col) { return mw == nullptr || ((mw[col >> 5] >> (col & 31)) & 1u); };
     const U4 x = philox4x32_10(c.agent_offset + (uint32_t)i, (uint32_t)c.step0,
                                (uint32_t)(c.step0 >> 32), STREAM_POLICY, c.seed_lo, c.seed_hi);
-    const bool explore = !deterministic && (unsigned long long)x.x < thr;
+    const bool explore = !(deterministic & 1) && (unsigned long long)x.x < thr;
     T m = neg_inf<T>();
     for (int col = lane; col < c.A; col += 64)
         if (ok(col)) m = row[col] > m ? row[col] : m;
@@ -1405,6 +1408,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_select_large(Ctx<T> c, EnvCtx ev
             k -= cnt;
         }
     }
+    if (act < 0 && (deterministic & 2) && mw != nullptr && !explore) act = (int)mulhi32(x.z, (uint32_t)c.A);  // see k_select
     if (lane == 0) out[i] = act;
 }
 

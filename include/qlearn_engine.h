@@ -122,7 +122,12 @@ int qe_set_agent_offset(qe_engine* e, uint32_t offset); /* draw-protocol id of l
  * choose_actions and all eight variants behind it (q_learning_optimal.py:263-726): one kernel
  * family, same distribution, draws per oracle/draws.py.  masks: n*A bytes or NULL.
  * Returns -1 in out_actions[i] when agent i has no selectable action (as :302, :348).
- * Consumes one step index. */
+ * `deterministic`: bit 0 = greedy selection (exploration rate ignored); bit 1 (QE_SELECT_NUMPY_EMPTY_MASK)
+ * = the NumPy variants' treatment of an agent whose mask has no valid action: its greedy pick is
+ * uniform over ALL actions (where(mask, Q, -inf) ties everywhere, :497-503, :618-628), only its
+ * exploratory pick is impossible (-1; the reference raises IndexError, :470).  Consumes one step index. */
+#define QE_SELECT_DETERMINISTIC 1
+#define QE_SELECT_NUMPY_EMPTY_MASK 2
 int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint8_t* masks,
                       double exploration_rate, int32_t deterministic, int32_t* out_actions);
 

@@ -145,6 +145,14 @@ class InjectedDraws:
     def _explores(self, i: int) -> bool:
         return int(self._x[0][i]) < self._thr
 
+    def skip_choice(self) -> None:
+        """An agent of a list variant had no candidate and returned -1 WITHOUT calling ``choice``
+        (reference :302, :348).  In deterministic calls the shim counts ``choice`` calls to know which
+        agent is being served, so the oracle tells it about the agent that made none.  (The real
+        reference cannot; the golden cases therefore contain no such agent.)"""
+        if self._batch or self._deterministic or self._cur < 0:
+            self._choice_calls += 1
+
     def choice(self, seq):
         n = len(seq)
         if n == 0:

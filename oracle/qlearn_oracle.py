@@ -69,7 +69,7 @@ class OracleQLearning:
                     best, cand = v, [j]
                 elif v == best:
                     cand.append(j)
-        return self._rng.choice(cand) if cand else -1
+        return self._rng.choice(cand) if cand else self._no_candidate()
 
     def choose_action_vec(self, state, exploration_rate, *, deterministic=False):
         # :402-430 -- NumPy row max + where(); uses ``_rng.random()`` instead of ``uniform``.
@@ -88,6 +88,13 @@ class OracleQLearning:
             mq = np.where(mask, self.q_table[state], -np.inf)
             cand = np.where(mq == np.max(mq))[0]
         return self._rng.choice(cand)
+
+    def _no_candidate(self):
+        # reference :302, :348 return -1 here; the draw shim is told that this agent drew nothing
+        skip = getattr(self._rng, "skip_choice", None)
+        if skip is not None:
+            skip()
+        return -1
 
     # ------------------------------------------------------------------ selection, batched forms
     def choose_actions_iter(self, states, exploration_rate, *, deterministic=False, action_masks=None):

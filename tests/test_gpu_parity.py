@@ -71,6 +71,45 @@ def test_select_matches_reference_golden(k):
     assert algo.step_counter == step + 1
 
 
+@pytest.mark.parametrize("n", [1, 3, 40, 300])
+@pytest.mark.parametrize("det", [False, True])
+@pytest.mark.parametrize("eps", [0.0, 0.5, 1.0])
+def test_agents_without_valid_action_follow_each_variant(n, det, eps):
+    """Agent 0's mask is all zeros.  The reference's list variants return -1 for it (:302, :348); its
+    NumPy variants tie every action at -inf, so the greedy pick is uniform over ALL actions and only an
+    exploratory pick raises IndexError (:470, :618-628).  The oracle was checked against the real
+    reference on exactly this grid (identical on all 96 combinations)."""
+    from oracle.draws import InjectedDraws
+    from oracle.qlearn_oracle import OracleQLearning
+
+    Algo = _product()[0]
+    S, A = 6, 5
+    q = (np.arange(S * A, dtype=np.float64).reshape(S, A) % 7).astype(np.float32)
+    states = (np.arange(n) % S).astype(np.int32)
+    masks = np.ones((n, A), dtype=np.int32)
+    masks[0] = 0
+    for method in ("choose_actions", "choose_actions_iter", "choose_actions_vec_iter", "choose_masked_actions_vec"):
+        results = []
+        for side in ("oracle", "product"):
+            if side == "oracle":
+                algo = OracleQLearning(S, A, 0.9, dtype=np.float32)
+                algo._rng = algo._np_rng = shim = InjectedDraws(7)
+                shim.begin(3, n, eps, deterministic=det)
+            else:
+                algo = Algo(S, A, 0.9, seed=7)
+                algo.step_counter = 3
+            algo.q_table = q.copy()
+            try:
+                if method == "choose_masked_actions_vec":
+                    out = getattr(algo, method)(states, masks, eps, deterministic=det)
+                else:
+                    out = getattr(algo, method)(states, eps, deterministic=det, action_masks=masks)
+                results.append(("ok", np.asarray(out).tolist()))
+            except IndexError:
+                results.append(("IndexError", None))
+        assert results[0] == results[1], (method, results)
+
+
 # ------------------------------------------------------------------------------- learning
 @pytest.mark.parametrize("k", range(len(LEARN_CASES)))
 @pytest.mark.parametrize("fn", ["learn", "learn_vec"])

@@ -30,7 +30,11 @@ while time.time() < t_end:
     masks = None
     if masked:
         masks = (rng.random((n, A)) < 0.5).astype(np.int32)
-        masks[np.arange(n), rng.integers(A, size=n)] = 1
+        if len(sys.argv) > 3 and sys.argv[3] == "empty":  # some agents without any valid action
+            masks[rng.random(n) < 0.9, rng.integers(A)] = 1
+            masks[rng.random(n) < 0.1] = 0
+        else:
+            masks[np.arange(n), rng.integers(A, size=n)] = 1
     algo, ref = Algo(S, A, 0.9, seed=seed, dtype=np.dtype(dt)), OracleQLearning(S, A, 0.9, dtype=np.dtype(dt))
     algo.q_table = q0
     algo.step_counter = step
