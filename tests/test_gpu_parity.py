@@ -110,6 +110,32 @@ def test_agents_without_valid_action_follow_each_variant(n, det, eps):
         assert results[0] == results[1], (method, results)
 
 
+def test_agents_without_valid_action_match_reference_golden():
+    """The same situation against the fixture generated from the real reference (tests/golden/empty_mask.npz)."""
+    Algo = _product()[0]
+    g = np.load(GOLDEN / "empty_mask.npz")
+    S, A, seed, step = (int(v) for v in g["meta"])
+    for k in range(int(g["count"])):
+        n, det, eps100 = (int(v) for v in g[f"c{k}_cfg"])
+        method, eps = str(g[f"c{k}_method"]), eps100 / 100.0
+        algo = Algo(S, A, 0.9, seed=seed, dtype=np.float64)
+        algo.q_table = g["q"]
+        algo.step_counter = step
+        states = (np.arange(n) % S).astype(np.int32)
+        masks = np.ones((n, A), dtype=np.int32)
+        masks[0] = 0
+        try:
+            if method == "choose_masked_actions_vec":
+                got = getattr(algo, method)(states, masks, eps, deterministic=bool(det))
+            else:
+                got = getattr(algo, method)(states, eps, deterministic=bool(det), action_masks=masks)
+            raised = 0
+        except IndexError:
+            got, raised = np.zeros(0, dtype=np.int32), 1
+        assert raised == int(g[f"c{k}_raised"]), (k, method, n, det, eps)
+        assert np.array_equal(np.asarray(got, dtype=np.int32), g[f"c{k}_actions"]), (k, method, n, det, eps)
+
+
 # ------------------------------------------------------------------------------- learning
 @pytest.mark.parametrize("k", range(len(LEARN_CASES)))
 @pytest.mark.parametrize("fn", ["learn", "learn_vec"])

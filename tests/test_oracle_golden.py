@@ -75,3 +75,31 @@ def test_closed_loop_trace_matches_reference(name):
     assert np.array_equal(got["final_obs"], g[f"{name}/final_obs"])
     assert np.array_equal(got["agent_rewards"], g[f"{name}/agent_rewards"])
     assert np.array_equal(got["final_sched"], g[f"{name}/final_sched"])
+
+
+def test_agents_without_valid_action_match_reference():
+    """tests/golden/empty_mask.npz (real reference, agent 0 with an all-zero mask): -1 from the list
+    variants, a uniform pick over ALL actions from the greedy NumPy variants, IndexError when such an
+    agent explores."""
+    g = np.load(GOLDEN / "empty_mask.npz")
+    S, A, seed, step = (int(v) for v in g["meta"])
+    for k in range(int(g["count"])):
+        n, det, eps100 = (int(v) for v in g[f"c{k}_cfg"])
+        method, eps = str(g[f"c{k}_method"]), eps100 / 100.0
+        algo = OracleQLearning(S, A, 0.9)
+        algo.q_table = g["q"].copy()
+        algo._rng = algo._np_rng = shim = InjectedDraws(seed)
+        shim.begin(step, n, eps, deterministic=bool(det))
+        states = (np.arange(n) % S).astype(np.int32)
+        masks = np.ones((n, A), dtype=np.int32)
+        masks[0] = 0
+        try:
+            if method == "choose_masked_actions_vec":
+                got = getattr(algo, method)(states, masks, eps, deterministic=bool(det))
+            else:
+                got = getattr(algo, method)(states, eps, deterministic=bool(det), action_masks=masks)
+            raised = 0
+        except IndexError:
+            got, raised = np.zeros(0, dtype=np.int32), 1
+        assert raised == int(g[f"c{k}_raised"]), (k, method, n, det, eps)
+        assert np.array_equal(np.asarray(got, dtype=np.int32), g[f"c{k}_actions"]), (k, method, n, det, eps)
