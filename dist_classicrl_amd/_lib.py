@@ -65,6 +65,7 @@ _U32P = C.POINTER(C.c_uint32)
 _U8P = C.POINTER(C.c_uint8)
 _F32P = C.POINTER(C.c_float)
 _F64P = C.POINTER(C.c_double)
+_I64P = C.POINTER(C.c_int64)
 
 # name -> (restype, argtypes); must list every symbol include/qlearn_engine.h declares
 PROTOTYPES = {
@@ -103,6 +104,14 @@ PROTOTYPES = {
     "qe_delta_log_reset": (C.c_int, [_P]),
     "qe_delta_apply_dev": (C.c_int, [_P, _P, C.c_int64]),
     "qe_delta_apply_skip_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64]),
+    "qe_replay_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
+    "qe_replay_destroy": (C.c_int, [_P]),
+    "qe_replay_push": (C.c_int, [_P, _I64P, _I64P, _F64P, _I64P, _U8P, C.c_int64]),
+    "qe_replay_len": (C.c_int64, [_P]),
+    "qe_replay_position": (C.c_int64, [_P]),
+    "qe_replay_full": (C.c_int32, [_P]),
+    "qe_replay_gather": (C.c_int, [_P, _I64P, C.c_int64, _I64P, _I64P, _F64P, _I64P, _U8P]),
+    "qe_replay_learn": (C.c_int, [_P, _P, _I64P, C.c_int64, C.c_double, C.c_int32]),
 }
 
 _lib = None

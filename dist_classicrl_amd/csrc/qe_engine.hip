@@ -834,24 +834,8 @@ int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint
 }
 
 // ---- learning --------------------------------------------------------------------------------
-int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const float* rewards,
-             const int32_t* next_states, const uint8_t* terminated, int64_t n, double lr,
-             const uint8_t* next_masks, int32_t mode) {
-    if (n == 0) return QE_OK;
-    if (n < 0 || !states || !actions || !rewards || !next_states || !terminated)
-        return fail(QE_ERR_INVALID, "bad argument");
-    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
-    if (int rc = check_indices(states, n, e->S, "states")) return rc;
-    if (int rc = check_indices(actions, n, e->A, "actions")) return rc;
-    // the sequential form never reads the next-state row of a terminated transition
-    // (q_learning_optimal.py:756-763): such entries are re-pointed at the written row.
-    std::vector<int32_t> nxt(next_states, next_states + n);
-    for (int64_t i = 0; i < n; ++i) {
-        if (terminated[i] && mode == QE_LEARN_ITER) nxt[(size_t)i] = states[i];
-        else if (nxt[(size_t)i] < 0 || nxt[(size_t)i] >= e->S)
-            return fail(QE_ERR_INDEX, "next_states[%lld] = %d is out of range", (long long)i, (int)nxt[(size_t)i]);
-    }
-    HIP_TRY(hipSetDevice(e->device));
+// Batch buffers of the unfused learn path (device side of qe_learn / qe_replay_learn).
+static int learn_buffers(qe_engine* e, int64_t n) {
     const size_t un = (size_t)n;
     HIP_TRY(e->b_s.ensure(un)); HIP_TRY(e->b_a.ensure(un)); HIP_TRY(e->b_n.ensure(un));
     HIP_TRY(e->b_r.ensure(un)); HIP_TRY(e->b_term.ensure(un)); HIP_TRY(e->b_pred.ensure(un * 8));
@@ -862,23 +846,17 @@ int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const 
         HIP_TRY(e->b_bitmap.ensure(words));
         HIP_TRY(hipMemsetAsync(e->b_bitmap.p, 0, e->b_bitmap.cap * 4, e->stream));
     }
-    HIP_TRY(hipMemcpyAsync(e->b_s.p, states, n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->b_a.p, actions, n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->b_n.p, nxt.data(), n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->b_r.p, rewards, n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->b_term.p, terminated, n, hipMemcpyHostToDevice, e->stream));
-    std::vector<uint32_t> packed;
-    if (next_masks) {
-        pack_masks(next_masks, n, e->A, packed);
-        HIP_TRY(e->b_mask.ensure(packed.size()));
-        HIP_TRY(hipMemcpyAsync(e->b_mask.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, e->stream));
-    }
+    return QE_OK;
+}
+
+// Runs the update kernels over the n transitions already sitting in the batch buffers and waits.
+static int learn_launch(qe_engine* e, int64_t n, double lr, bool masked, int32_t mode) {
     const unsigned long long thr0 = 0;
     HIP_TRY(e->thr.ensure(1)); HIP_TRY(e->lr.ensure(1));
     HIP_TRY(hipMemcpyAsync(e->thr.p, &thr0, 8, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->lr.p, &lr, 8, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
-    const EnvCtx ev = make_envctx(e, nullptr, e->b_mask.p, next_masks ? 1 : 0);
+    const EnvCtx ev = make_envctx(e, nullptr, e->b_mask.p, masked ? 1 : 0);
     const bool large = e->ld > 256;
     auto go = [&](auto tag) {
         using T = decltype(tag);
@@ -900,6 +878,39 @@ int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const 
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     return QE_OK;
+}
+
+int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const float* rewards,
+             const int32_t* next_states, const uint8_t* terminated, int64_t n, double lr,
+             const uint8_t* next_masks, int32_t mode) {
+    if (n == 0) return QE_OK;
+    if (n < 0 || !states || !actions || !rewards || !next_states || !terminated)
+        return fail(QE_ERR_INVALID, "bad argument");
+    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
+    if (int rc = check_indices(states, n, e->S, "states")) return rc;
+    if (int rc = check_indices(actions, n, e->A, "actions")) return rc;
+    // the sequential form never reads the next-state row of a terminated transition
+    // (q_learning_optimal.py:756-763): such entries are re-pointed at the written row.
+    std::vector<int32_t> nxt(next_states, next_states + n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (terminated[i] && mode == QE_LEARN_ITER) nxt[(size_t)i] = states[i];
+        else if (nxt[(size_t)i] < 0 || nxt[(size_t)i] >= e->S)
+            return fail(QE_ERR_INDEX, "next_states[%lld] = %d is out of range", (long long)i, (int)nxt[(size_t)i]);
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rc = learn_buffers(e, n)) return rc;
+    HIP_TRY(hipMemcpyAsync(e->b_s.p, states, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_a.p, actions, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_n.p, nxt.data(), n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_r.p, rewards, n * 4, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->b_term.p, terminated, n, hipMemcpyHostToDevice, e->stream));
+    std::vector<uint32_t> packed;
+    if (next_masks) {
+        pack_masks(next_masks, n, e->A, packed);
+        HIP_TRY(e->b_mask.ensure(packed.size()));
+        HIP_TRY(hipMemcpyAsync(e->b_mask.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, e->stream));
+    }
+    return learn_launch(e, n, lr, next_masks != nullptr, mode);
 }
 
 // ---- environments ------------------------------------------------------------------------------
@@ -1159,6 +1170,140 @@ int qe_delta_apply_skip_dev(qe_engine* e, const void* dev_entries, int64_t count
                        (const DeltaEntry*)dev_entries, count, skip_begin, skip_end - skip_begin);
     HIP_TRY(hipGetLastError());
     return QE_OK;
+}
+
+// ---- experience replay ring ---------------------------------------------------------------------
+struct qe_replay {
+    int device = 0;
+    int64_t capacity = 0, position = 0;
+    bool full = false;
+    DevBuf<int64_t> s, a, n, idx, o_s, o_a, o_n;
+    DevBuf<double> r, o_r;
+    DevBuf<uint8_t> d, o_d;
+    DevBuf<unsigned> bad;
+    hipStream_t stream = nullptr;
+};
+
+int qe_replay_create(qe_replay** out, int32_t device, int64_t capacity) {
+    if (!out || capacity <= 0) return fail(QE_ERR_INVALID, "capacity must be > 0");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(QE_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= count) return fail(QE_ERR_INVALID, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    qe_replay* rb = new qe_replay();
+    rb->device = device; rb->capacity = capacity;
+    const size_t c = (size_t)capacity;
+    hipError_t err = rb->s.ensure(c);
+    if (err == hipSuccess) err = rb->a.ensure(c);
+    if (err == hipSuccess) err = rb->n.ensure(c);
+    if (err == hipSuccess) err = rb->r.ensure(c);
+    if (err == hipSuccess) err = rb->d.ensure(c);
+    if (err == hipSuccess) err = rb->bad.ensure(1);
+    if (err == hipSuccess) err = hipStreamCreate(&rb->stream);
+    if (err != hipSuccess) { qe_replay_destroy(rb); return fail(QE_ERR_OOM, "replay allocation failed: %s", hipGetErrorString(err)); }
+    *out = rb;
+    return QE_OK;
+}
+
+int qe_replay_destroy(qe_replay* rb) {
+    if (!rb) return QE_OK;
+    (void)hipSetDevice(rb->device);
+    if (rb->stream) { (void)hipStreamSynchronize(rb->stream); (void)hipStreamDestroy(rb->stream); }
+    rb->s.release(); rb->a.release(); rb->n.release(); rb->r.release(); rb->d.release(); rb->idx.release();
+    rb->o_s.release(); rb->o_a.release(); rb->o_n.release(); rb->o_r.release(); rb->o_d.release(); rb->bad.release();
+    delete rb;
+    return QE_OK;
+}
+
+int qe_replay_push(qe_replay* rb, const int64_t* states, const int64_t* actions, const double* rewards,
+                   const int64_t* next_states, const uint8_t* done, int64_t n) {
+    if (!rb || n < 0 || (n > 0 && (!states || !actions || !rewards || !next_states || !done)))
+        return fail(QE_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(rb->device));
+    const int64_t cap = rb->capacity;
+    int64_t first = 0;
+    if (n > cap) {  // only the last `capacity` pushes survive; the ring position still advances by n
+        first = n - cap;
+        rb->position = (rb->position + first) % cap;
+        rb->full = true;
+    }
+    for (int64_t done_n = first; done_n < n;) {  // at most two contiguous pieces
+        const int64_t piece = std::min(n - done_n, cap - rb->position);
+        const int64_t at = rb->position;
+        HIP_TRY(hipMemcpyAsync(rb->s.p + at, states + done_n, piece * 8, hipMemcpyHostToDevice, rb->stream));
+        HIP_TRY(hipMemcpyAsync(rb->a.p + at, actions + done_n, piece * 8, hipMemcpyHostToDevice, rb->stream));
+        HIP_TRY(hipMemcpyAsync(rb->r.p + at, rewards + done_n, piece * 8, hipMemcpyHostToDevice, rb->stream));
+        HIP_TRY(hipMemcpyAsync(rb->n.p + at, next_states + done_n, piece * 8, hipMemcpyHostToDevice, rb->stream));
+        HIP_TRY(hipMemcpyAsync(rb->d.p + at, done + done_n, piece, hipMemcpyHostToDevice, rb->stream));
+        rb->position = (rb->position + piece) % cap;
+        if (rb->position == 0) rb->full = true;  // experience_replay.py:85-86
+        done_n += piece;
+    }
+    HIP_TRY(hipStreamSynchronize(rb->stream));  // the host arrays are borrowed for the call only
+    return QE_OK;
+}
+
+int64_t qe_replay_len(qe_replay* rb) { return rb ? (rb->full ? rb->capacity : rb->position) : 0; }
+int64_t qe_replay_position(qe_replay* rb) { return rb ? rb->position : 0; }
+int32_t qe_replay_full(qe_replay* rb) { return rb && rb->full ? 1 : 0; }
+
+static int replay_indices(qe_replay* rb, const int64_t* indices, int64_t n) {
+    // NumPy semantics of buffer[indices]: negative indices count from the end, anything else raises
+    std::vector<int64_t> idx(indices, indices + n);
+    for (int64_t i = 0; i < n; ++i) {
+        if (idx[(size_t)i] < 0) idx[(size_t)i] += rb->capacity;
+        if (idx[(size_t)i] < 0 || idx[(size_t)i] >= rb->capacity)
+            return fail(QE_ERR_INDEX, "index %lld is out of bounds for axis 0 with size %lld", (long long)indices[i],
+                        (long long)rb->capacity);
+    }
+    HIP_TRY(rb->idx.ensure((size_t)n));
+    HIP_TRY(hipMemcpyAsync(rb->idx.p, idx.data(), n * 8, hipMemcpyHostToDevice, rb->stream));
+    HIP_TRY(hipStreamSynchronize(rb->stream));
+    return QE_OK;
+}
+
+int qe_replay_gather(qe_replay* rb, const int64_t* indices, int64_t n, int64_t* states, int64_t* actions,
+                     double* rewards, int64_t* next_states, uint8_t* done) {
+    if (!rb || n < 0 || (n > 0 && (!indices || !states || !actions || !rewards || !next_states || !done)))
+        return fail(QE_ERR_INVALID, "bad argument");
+    if (n == 0) return QE_OK;
+    HIP_TRY(hipSetDevice(rb->device));
+    if (int rc = replay_indices(rb, indices, n)) return rc;
+    const size_t un = (size_t)n;
+    HIP_TRY(rb->o_s.ensure(un)); HIP_TRY(rb->o_a.ensure(un)); HIP_TRY(rb->o_n.ensure(un));
+    HIP_TRY(rb->o_r.ensure(un)); HIP_TRY(rb->o_d.ensure(un));
+    hipLaunchKernelGGL(k_replay_gather, dim3(grid_for(n, 256)), dim3(256), 0, rb->stream, (const int64_t*)rb->s.p,
+                       (const int64_t*)rb->a.p, (const double*)rb->r.p, (const int64_t*)rb->n.p, (const uint8_t*)rb->d.p,
+                       (const int64_t*)rb->idx.p, n, rb->o_s.p, rb->o_a.p, rb->o_r.p, rb->o_n.p, rb->o_d.p);
+    HIP_TRY(hipMemcpyAsync(states, rb->o_s.p, n * 8, hipMemcpyDeviceToHost, rb->stream));
+    HIP_TRY(hipMemcpyAsync(actions, rb->o_a.p, n * 8, hipMemcpyDeviceToHost, rb->stream));
+    HIP_TRY(hipMemcpyAsync(rewards, rb->o_r.p, n * 8, hipMemcpyDeviceToHost, rb->stream));
+    HIP_TRY(hipMemcpyAsync(next_states, rb->o_n.p, n * 8, hipMemcpyDeviceToHost, rb->stream));
+    HIP_TRY(hipMemcpyAsync(done, rb->o_d.p, n, hipMemcpyDeviceToHost, rb->stream));
+    HIP_TRY(hipStreamSynchronize(rb->stream));
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+int qe_replay_learn(qe_replay* rb, qe_engine* e, const int64_t* indices, int64_t n, double lr, int32_t mode) {
+    if (!rb || !e || n < 0 || (n > 0 && !indices)) return fail(QE_ERR_INVALID, "bad argument");
+    if (rb->device != e->device) return fail(QE_ERR_INVALID, "replay buffer and engine live on different devices");
+    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
+    if (n == 0) return QE_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rc = replay_indices(rb, indices, n)) return rc;
+    if (int rc = learn_buffers(e, n)) return rc;
+    HIP_TRY(hipMemsetAsync(rb->bad.p, 0, sizeof(unsigned), e->stream));
+    hipLaunchKernelGGL(k_replay_to_batch, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, (const int64_t*)rb->s.p,
+                       (const int64_t*)rb->a.p, (const double*)rb->r.p, (const int64_t*)rb->n.p, (const uint8_t*)rb->d.p,
+                       (const int64_t*)rb->idx.p, n, e->S, e->A, mode == QE_LEARN_ITER ? 1 : 0, e->b_s.p, e->b_a.p,
+                       e->b_r.p, e->b_n.p, e->b_term.p, rb->bad.p);
+    unsigned bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, rb->bad.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (bad) return fail(QE_ERR_INDEX, "%u sampled experiences hold a state / action outside the table", bad);
+    return learn_launch(e, n, lr, false, mode);
 }
 
 }  // extern "C"

@@ -1538,4 +1538,30 @@ __global__ void k_delta_apply_skip(T* q, const DeltaEntry* e, int64_t count, int
     atomicAdd(q + e[i].cell, (T)e[i].delta);
 }
 
+// ---- experience replay ring (experience_replay.py): gather of sampled entries ---------------------
+__global__ void k_replay_gather(const int64_t* rs, const int64_t* ra, const double* rr, const int64_t* rn,
+                                const uint8_t* rd, const int64_t* idx, int64_t n, int64_t* s, int64_t* a,
+                                double* r, int64_t* s2, uint8_t* d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = idx[i];
+    s[i] = rs[j]; a[i] = ra[j]; r[i] = rr[j]; s2[i] = rn[j]; d[i] = rd[j];
+}
+// the same, straight into the batch buffers of qe_learn (narrowed to its types; `bad` counts entries
+// whose state / action / next state does not fit the table)
+__global__ void k_replay_to_batch(const int64_t* rs, const int64_t* ra, const double* rr, const int64_t* rn,
+                                  const uint8_t* rd, const int64_t* idx, int64_t n, int64_t S, int32_t A, int iter_mode,
+                                  int32_t* s, int32_t* a, float* r, int32_t* s2, uint8_t* d, unsigned* bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t j = idx[i];
+    const int64_t st = rs[j], ac = ra[j];
+    int64_t nx = rn[j];
+    const bool done = rd[j] != 0;
+    // learn_iter never reads the next-state row of a terminated transition (qe_learn does the same)
+    if (done && iter_mode) nx = st;
+    if (st < 0 || st >= S || ac < 0 || ac >= A || nx < 0 || nx >= S) { atomicAdd(bad, 1u); return; }
+    s[i] = (int32_t)st; a[i] = (int32_t)ac; r[i] = (float)rr[j]; s2[i] = (int32_t)nx; d[i] = done ? 1 : 0;
+}
+
 }  // namespace qe

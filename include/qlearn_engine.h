@@ -192,6 +192,25 @@ int qe_delta_apply_dev(qe_engine* e, const void* dev_entries, int64_t count);
 int qe_delta_apply_skip_dev(qe_engine* e, const void* dev_entries, int64_t count, int64_t skip_begin,
                             int64_t skip_end);
 
+/* ---- experience replay (algorithms/buffers/experience_replay.py:13-120; WIP and unused upstream) --
+ * Ring buffer of (state, action, reward, next_state, done) in HBM.  Index SELECTION stays with the
+ * caller (the reference draws `rng.choice(len, batch, replace=False)` from a NumPy Generator, :103-105;
+ * the Python mirror does exactly that), the library stores, gathers and learns.
+ *   qe_replay_create  <- ExperienceReplay.__init__ :56-66       qe_replay_push   <- push :68-86 (n in order)
+ *   qe_replay_len     <- __len__ :111-120                       qe_replay_gather <- the fancy indexing of sample :103-109
+ *   qe_replay_learn   : gather + qe_learn without leaving the device (what a replay-driven trainer does next) */
+typedef struct qe_replay qe_replay;
+int qe_replay_create(qe_replay** out, int32_t device, int64_t capacity);
+int qe_replay_destroy(qe_replay* rb);
+int qe_replay_push(qe_replay* rb, const int64_t* states, const int64_t* actions, const double* rewards,
+                   const int64_t* next_states, const uint8_t* done, int64_t n);
+int64_t qe_replay_len(qe_replay* rb);
+int64_t qe_replay_position(qe_replay* rb);
+int32_t qe_replay_full(qe_replay* rb);
+int qe_replay_gather(qe_replay* rb, const int64_t* indices, int64_t n, int64_t* states, int64_t* actions,
+                     double* rewards, int64_t* next_states, uint8_t* done);
+int qe_replay_learn(qe_replay* rb, qe_engine* e, const int64_t* indices, int64_t n, double lr, int32_t mode);
+
 #ifdef __cplusplus
 }
 #endif
