@@ -4,7 +4,8 @@
 // Row view: a row of `A` Q-values (stride `ld`, multiple of 4) is spread over a group of L
 // consecutive lanes (L = power of two, 1..64, L*4 >= ld); lane `sub` holds columns 4*sub..4*sub+3
 // from one 16-byte (fp32) / two 16-byte (fp64) loads.  A 64-wide wavefront therefore handles 64/L
-// agents; reductions stay inside the group (`__shfl_*` with width L), no LDS round trip.
+// agents; reductions stay inside the group: DPP moves when the width is a compile-time constant of
+// 2/4/8/16 lanes, `__shfl_*` (ds_bpermute) otherwise.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

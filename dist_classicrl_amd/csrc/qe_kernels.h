@@ -11,7 +11,13 @@
 //   k_step_slow(t):  one workgroup; the few agents whose rows are shared in step t ("involved") run
 //                    the same work, their table accesses ordered by agent index per row (dataflow
 //                    rounds over an LDS hash of the shared rows) -- the exact sequential semantics
-//                    of learn_iter -- or, in VEC mode, read-all-then-atomicAdd (learn_vec, :819-891).
+//                    of learn_iter -- or, in VEC mode, read-all-then-accumulate per cell in agent
+//                    order (learn_vec / np.add.at, :819-891).
+//   wide mode (>= 2048 agents): k_token_round x R between the two works most involved agents off on
+//                    the whole chip (lowest pending toucher of every row goes first), k_advance runs
+//                    the selections that had to wait for them; k_compact / *_list walk compacted lists.
+//   k_rollout_persistent: <= 512 agents -- the whole loop in ONE launch on one CU, contention
+//                    tracked in LDS, one workgroup barrier per quiet step.
 //
 // Why that is exact: a row touched by a single agent in step t holds the same values at every
 // point of the reference's step t, so reading it once (after step t-1 completed: kernel boundary)
