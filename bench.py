@@ -161,10 +161,19 @@ def main() -> None:
             torch.cuda.synchronize()
         algo._lib.qe_synchronize(algo.handle)
 
-    _, _, _, sd = rt.run_steps(max(1, args.warmup), env, None)  # untimed warm-up (also resets the env)
+    def run_steps(steps, state):
+        """`run_steps`; the reference divides by the number of finished episodes (single_thread_runtime.py:67),
+        so a very short call in which no episode ends raises ZeroDivisionError AFTER all its work is done."""
+        try:
+            return rt.run_steps(steps, env, state)[3]
+        except ZeroDivisionError:
+            states, rewards = env.observe()
+            return {"states": states, "infos": [{}] * n, "rewards": rewards, "episode_rewards": []}
+
+    sd = run_steps(max(1, args.warmup), None)  # untimed warm-up (also resets the env)
     sync_all()
     t0 = time.perf_counter()
-    _, history, _, sd = rt.run_steps(args.steps, env, sd)  # EXACTLY K timed vector steps
+    sd = run_steps(args.steps, sd)  # EXACTLY K timed vector steps
     sync_all()
     elapsed = time.perf_counter() - t0
     stats = dict(rt.last_stats)
@@ -230,7 +239,7 @@ def main() -> None:
         },
         "device_region_ms": stats["kernel_ms"],
         "kernel_launches": stats["launches"],
-        "episodes": len(history),
+        "episodes": int(stats["episodes"]),
         "contested_agent_steps": stats["involved"],
     }
     if not args.no_cpu_baseline and n_gpus == 1:
