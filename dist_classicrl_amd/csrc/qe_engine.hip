@@ -424,8 +424,13 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             constexpr int LCV = decltype(lc)::value;
             // up to 512 threads the kernel is built with twice the vector-register budget (the BASELINE
             // shapes with 128 agents: 256 or 512 lanes)
-            if ((LCV == 2 || LCV == 4) && block <= 512)
-                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, (LCV == 2 || LCV == 4) ? 512 : 1024>), dim3(1),
+            constexpr int SMALL = (LCV == 2 || LCV == 4) ? 512 : 1024;
+            const bool lean = mode == QE_LEARN_ITER && !c.trace && !c.dlog;
+            if ((LCV == 2 || LCV == 4) && block <= 512 && lean)
+                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL, SMALL == 512>), dim3(1),
+                                   dim3(block), 0, e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+            else if ((LCV == 2 || LCV == 4) && block <= 512)
+                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL>), dim3(1),
                                    dim3(block), 0, e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
             else
                 hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, 1024>), dim3(1), dim3(block), 0,

@@ -864,9 +864,13 @@ __device__ __forceinline__ int ct_insert(PersistLds& l, int tb, int32_t row, uns
 #define QE_STAMP(k) do { } while (0)
 #endif
 
-template <typename T, class Env, int LC, int BLOCK = 1024>
+// LEAN = the launch is known to be a plain training rollout (sequential `learn`, no action trace, no
+// delta log): the compiler is told so, which removes three families of uniform branches and their
+// operands from the scalar-register budget of the loop.
+template <typename T, class Env, int LC, int BLOCK = 1024, bool LEAN = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx ev, long long steps, int flags) {
     __shared__ PersistLds lds;
+    if constexpr (LEAN) { c.mode = 0; c.trace = nullptr; c.dlog = nullptr; }
 #ifdef QE_STAMPS
     long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_last = wall_clock64();
