@@ -95,7 +95,7 @@ class OptimalQLearningBase:
         """Tuning knob, never changes results: ``"auto"``, ``"stepwise"`` (one kernel pair per vector
         step), ``"persistent"`` (one launch per rollout; needs <= 512 agents and agents x lanes-per-row
         <= 1024) or ``"wide"`` (step-wise, the ordered path spread over the whole chip; automatic
-        from 2048 agents)."""
+        from 2048 agents, both learn modes)."""
         code = {"auto": _lib.PATH_AUTO, "stepwise": _lib.PATH_STEPWISE, "persistent": _lib.PATH_PERSISTENT,
                 "wide": _lib.PATH_WIDE}[path]
         _lib.check(self._lib.qe_set_option(self._h, _lib.OPT_ROLLOUT_PATH, code))

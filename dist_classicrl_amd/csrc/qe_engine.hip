@@ -326,6 +326,37 @@ void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& e
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
     ++sl.launches;
     if (!slow) return;
+    if (c.tok && c.mode == QE_LEARN_VEC) {
+        // wide mode, learn_vec: increments of all involved agents from the pre-step table, then rounds that
+        // add them row by row in agent order, the one-workgroup clean-up, postponed selections
+        const int rounds = sl.rounds;
+        const dim3 cgrid(grid_for((c.N + 31) / 32, FAST_BLOCK));
+        const dim3 lgrid(std::min<unsigned>(grid.x, LISTED_GRID));
+        const int32_t* list0 = c.pend_list;  // nullptr: scan the bitmap
+        int launches = 3;
+        if (list0) {
+            hipLaunchKernelGGL((k_compact<T>), cgrid, block, 0, e->stream, c, (const uint32_t*)c.inv_bitmap, c.pend_list, 0);
+            ++launches;
+        }
+        hipLaunchKernelGGL((k_vec_inc<T, Env, LC>), list0 ? lgrid : grid, block, 0, e->stream, c, ev, list0);
+        for (int r = 0; r < rounds; ++r) {
+            if (list0 && r == LISTED_RECOMPACT) {
+                hipLaunchKernelGGL((k_compact<T>), cgrid, block, 0, e->stream, c, (const uint32_t*)c.inv_bitmap, c.inv_list, 1);
+                ++launches;
+            }
+            const bool second = list0 && r >= LISTED_RECOMPACT;
+            hipLaunchKernelGGL((k_vec_round<T>), lgrid, block, 0, e->stream, c, flags, r,
+                               (const int32_t*)(second ? c.inv_list : list0), second ? 1 : 0);
+        }
+        hipLaunchKernelGGL((k_step_slow<T, Env, LC>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev,
+                           (flags & ~FLAG_SELECT) | FLAG_VEC_INC_READY);
+        if (list0)
+            hipLaunchKernelGGL((k_advance_list<T, Env, LC>), lgrid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1, list0);
+        else
+            hipLaunchKernelGGL((k_advance<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1);
+        sl.launches += rounds + launches;
+        return;
+    }
     if (c.tok) {  // wide mode: token rounds on the whole chip, clean-up, postponed selections
         const int rounds = sl.rounds;
         if (c.pend_list) {
@@ -399,7 +430,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and num_agents * lanes_per_row <= 1024 (have %lld lanes)",
                     (long long)lanes);
     // wide mode: exact sequential updates, many agents, ordered path spread over the chip
-    const bool wide = learn && !persistent && mode == QE_LEARN_ITER &&
+    const bool wide = learn && !persistent &&
                       (e->opt_path == 3 || (e->opt_path == 0 && env->N >= 2048));
     if (wide) {
         if (!e->tok) {

@@ -43,6 +43,7 @@ constexpr int FLAG_PRED_FROM_TABLE = 8;  // qe_learn: Q[s,a] is not carried, rea
 constexpr int FLAG_ACCOUNT = 16;         // episode-return bookkeeping (rollouts; not qe_learn)
 constexpr int FLAG_NO_STAMPS = 32;       // persistent kernel: contention is tracked in LDS instead
 constexpr int FLAG_T_MINUS_1 = 64;       // the step counter has already been advanced (k_advance)
+constexpr int FLAG_VEC_INC_READY = 128;  // VEC, wide mode: the increments of the involved agents are already in vinc
 constexpr uint32_t TOK_INF = 0xFFFFFFFFu;
 constexpr unsigned ERR_EMPTY_CHOICE = 3u;  // Ctrl::error: a fused selection found no selectable action
 
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
                 if (c.tok) {  // wide mode: enter the token rounds (k_token_round) and the late selection
                     atomicOr(&c.adv_bitmap[i >> 5], 1u << (i & 31));
                     atomicMin(&c.tok[s], (uint32_t)i);
-                    if (c.term[i] == 0 && n != s) atomicMin(&c.tok[n], (uint32_t)i);
+                    // (learn_vec orders only the additions into a row: no reader token)
+                    if (c.mode == 0 && c.term[i] == 0 && n != s) atomicMin(&c.tok[n], (uint32_t)i);
                 }
             }
             return;
@@ -472,7 +474,14 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
         // are then accumulated in agent order by the first of them (exactly np.add.at).
         double* inc = c.vinc;
         uint32_t* cells = reinterpret_cast<uint32_t*>(lds.t_next);
-        for (int p0 = 0; p0 < M; p0 += ngrp) {  // pass A: reads
+        const bool inc_ready = (flags & FLAG_VEC_INC_READY) != 0;  // wide mode: k_vec_inc did pass A
+        if (inc_ready) {
+            for (int pos = tid; pos < min(M, 2 * CAP); pos += BS) {
+                const int64_t i = c.inv_list[pos];
+                cells[pos] = (uint32_t)((int64_t)load_live(c.s + i) * c.ld + load_live(c.a + i));
+            }
+        }
+        for (int p0 = 0; p0 < (inc_ready ? 0 : M); p0 += ngrp) {  // pass A: reads
             const int pos = p0 + grp;
             if (pos < M) {
                 const int64_t i = c.inv_list[pos];
@@ -1283,6 +1292,77 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_token_round_list(Ctx<T> c, EnvCt
         const int64_t i = list[p];
         if (!((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u)) continue;
         token_round_agent<T, Env, LC>(c, ev, flags, round, i, sub, t);
+    }
+}
+
+// ---- wide mode, learn_vec ---------------------------------------------------------------------------
+// Read-all-then-accumulate on the whole chip: k_vec_inc forms the increment of every involved agent from
+// the pre-step table (the fast kernel wrote only rows that nobody else touches); the rounds then add the
+// increments row by row in agent order -- the lowest pending writer of a row goes first, each addition
+// in float64 rounded into the table dtype, i.e. np.add.at's order and rounding -- and k_step_slow
+// finishes the rows with long queues from the same increments.
+template <typename T, class Env, int LC = 0>
+__device__ __forceinline__ void vec_inc_agent(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub, long long t) {
+    const int32_t s = c.s[i], a = c.a[i], n = c.n[i];
+    const bool term = c.term[i] != 0;
+    const Row4<T> row = load_row4(c.q, n, c.ld, sub);
+    const T m = row_max_valid<LC>(row, Env::valid4(ev, i, n, sub), c.L);
+    if (sub == 0) {
+        const int64_t cell = (int64_t)s * c.ld + a;
+        const T q0 = c.q[cell];
+        const Hyper h = make_hyper(c, c.lr[t]);
+        double u;
+        if constexpr (sizeof(T) == 4) u = Td<float>::vec_inc(q0, c.r[i], m, term, h);
+        else u = Td<double>::delta(q0, c.r[i], m, term, h, true);
+        c.vinc[i] = u;
+        log_delta(c, t, i, cell, (T)u);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void vec_round_agent(const Ctx<T>& c, int flags, int round, int64_t i, long long t) {
+    const int32_t s = c.s[i];
+    uint32_t* cur = c.tok + (int64_t)(round & 1) * c.S;
+    uint32_t* nxt = c.tok + (int64_t)((round & 1) ^ 1) * c.S;
+    if (cur[s] == (uint32_t)i) {
+        cur[s] = TOK_INF;
+        T* cell = c.q + (int64_t)s * c.ld + c.a[i];
+        *cell = (T)((double)*cell + c.vinc[i]);
+        if (flags & FLAG_ACCOUNT) account(c, t, i, c.r[i], c.term[i] != 0);
+        atomicAnd(&c.inv_bitmap[i >> 5], ~(1u << (i & 31)));
+    } else {
+        atomicMin(&nxt[s], (uint32_t)i);
+    }
+}
+
+template <typename T, class Env, int LC = 0>
+__global__ __launch_bounds__(FAST_BLOCK) void k_vec_inc(Ctx<T> c, EnvCtx ev, const int32_t* list) {
+    const int sub = (int)(threadIdx.x & (c.L - 1));
+    const long long t = c.ctrl->t_local;
+    const int gpb = FAST_BLOCK >> c.lshift;
+    if (list) {  // compacted list of the involved agents
+        const int count = (int)c.ctrl->pend_count[0];
+        for (int p = (int)blockIdx.x * gpb + (int)(threadIdx.x >> c.lshift); p < count; p += (int)gridDim.x * gpb)
+            vec_inc_agent<T, Env, LC>(c, ev, list[p], sub, t);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * gpb + (threadIdx.x >> c.lshift); i < c.N; i += (int64_t)gridDim.x * gpb)
+            if ((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u) vec_inc_agent<T, Env, LC>(c, ev, i, sub, t);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(FAST_BLOCK) void k_vec_round(Ctx<T> c, int flags, int round, const int32_t* list, int which) {
+    const long long t = c.ctrl->t_local;
+    const int64_t stride = (int64_t)gridDim.x * FAST_BLOCK;
+    if (list) {
+        const int64_t count = (int64_t)c.ctrl->pend_count[which];
+        for (int64_t p = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x; p < count; p += stride) {
+            const int64_t i = list[p];
+            if ((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u) vec_round_agent<T>(c, flags, round, i, t);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x; i < c.N; i += stride)
+            if ((c.inv_bitmap[i >> 5] >> (i & 31)) & 1u) vec_round_agent<T>(c, flags, round, i, t);
     }
 }
 
