@@ -295,6 +295,10 @@ class OptimalQLearningBase:
         """Batch semantics: all reads precede all writes; colliding updates accumulate (:819-891)."""
         self._learn(states, actions, rewards, next_states, terminated, lr, next_action_masks, _lib.LEARN_VEC)
 
+    def _learn_vec(self, states, actions, rewards, next_states, terminated, lr, next_action_masks=None):
+        """The reference's private worker behind ``learn_vec`` (:853-891); same thing here."""
+        self.learn_vec(states, actions, rewards, next_states, terminated, lr, next_action_masks)
+
     def single_learn(self, state, action, reward, next_state, terminated, lr, next_action_mask=None):
         masks = None if next_action_mask is None else np.asarray(next_action_mask)[None, :]
         self._learn([state], [action], [reward], [next_state], [terminated], lr, masks, _lib.LEARN_ITER)
