@@ -43,6 +43,7 @@ constexpr int FLAG_PRED_FROM_TABLE = 8;  // qe_learn: Q[s,a] is not carried, rea
 constexpr int FLAG_ACCOUNT = 16;         // episode-return bookkeeping (rollouts; not qe_learn)
 constexpr int FLAG_NO_STAMPS = 32;       // persistent kernel: contention is tracked in LDS instead
 constexpr int FLAG_T_MINUS_1 = 64;       // the step counter has already been advanced (k_advance)
+constexpr int FLAG_PRESTAGED = 256;      // ordered path: the caller has staged the transitions in LDS (persistent kernel)
 constexpr int FLAG_VEC_INC_READY = 128;  // VEC, wide mode: the increments of the involved agents are already in vinc
 constexpr uint32_t TOK_INF = 0xFFFFFFFFu;
 constexpr unsigned ERR_EMPTY_CHOICE = 3u;  // Ctrl::error: a fused selection found no selectable action
@@ -542,8 +543,16 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
         __syncthreads();
         for (int id = tid; id < 2 * M; id += BS) {
             const int pos = id >> 1;
-            const int64_t i = list[pos];
-            const LiveAgent<T> g = live_agent(c, i);
+            const bool prestaged = (flags & FLAG_PRESTAGED) != 0;
+            int64_t i;
+            LiveAgent<T> g;
+            if (prestaged) {  // written straight from the owners' registers (persistent kernel)
+                i = lds.a_agent[pos];
+                g.s = lds.a_s[pos]; g.a = lds.a_a[pos]; g.n = lds.a_n[pos]; g.r = lds.a_r[pos]; g.term = lds.a_term[pos] != 0;
+            } else {
+                i = list[pos];
+                g = live_agent(c, i);
+            }
             const bool need = (id & 1) == 0 || !g.term;  // id even: W(row s); odd: R(row n), unless terminated
             int slot = -1;
             if (need) {
@@ -567,8 +576,10 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
             if ((id & 1) == 0) {
                 lds.a_state[pos] = 0;
                 lds.a_mready[pos] = 0;
-                lds.a_agent[pos] = (int)i; lds.a_s[pos] = g.s; lds.a_a[pos] = g.a; lds.a_n[pos] = g.n;
-                lds.a_r[pos] = g.r; lds.a_term[pos] = g.term ? 1 : 0;
+                if (!prestaged) {
+                    lds.a_agent[pos] = (int)i; lds.a_s[pos] = g.s; lds.a_a[pos] = g.a; lds.a_n[pos] = g.n;
+                    lds.a_r[pos] = g.r; lds.a_term[pos] = g.term ? 1 : 0;
+                }
             }
         }
         __syncthreads();
@@ -767,7 +778,8 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
 
     // ---- bookkeeping, stamp clean-up, then select(t+1) + env.step(t+1) for involved agents -----
     const int par = (int)(t & 1);
-    for (int pos = tid; pos < M; pos += BS) {
+    const bool tail_work = (flags & FLAG_ACCOUNT) || !(flags & FLAG_NO_STAMPS) || c.tok != nullptr;
+    for (int pos = tid; pos < (tail_work ? M : 0); pos += BS) {
         const int64_t i = c.inv_list[pos];
         const LiveAgent<T> g = live_agent(c, i);
         if (flags & FLAG_ACCOUNT) account(c, t, i, g.r, g.term);
@@ -848,6 +860,7 @@ struct PersistLds {
     float ep_ret[EP_STAGE];
     unsigned char pending[PERSIST_MAX_AGENTS];  // 1 while an agent's deferred update is outstanding
     alignas(16) unsigned char cold[320];  // the launch context, for the rare paths (see the kernel)
+    unsigned def_bits[PERSIST_MAX_AGENTS / 32];  // deferred agents of a step (general ordered path), by index
     unsigned busy[3];     // step t: some row has more than one toucher
     unsigned ep_n;
     unsigned n_def;       // agents whose update is deferred in this step
@@ -911,6 +924,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
         (&lds.ct_min[0][0])[k] = 0x7FFFFFFF;
     }
     for (int k = tid; k < PERSIST_MAX_AGENTS; k += (int)blockDim.x) lds.pending[k] = 0;
+    if (tid < PERSIST_MAX_AGENTS / 32) lds.def_bits[tid] = 0u;
     // The context is ~70 scalar registers; what only the rare paths need (agent arrays for the general
     // ordered path, log pointers for the periodic flush, the epilogue) is parked in LDS and fetched
     // when such a path runs, so that the quiet step does not pay for scalar-register spills.
@@ -1113,15 +1127,40 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
                     cc.inv_bitmap = cold.inv_bitmap; cc.inv_list = cold.inv_list; cc.vinc = cold.vinc;
                     cc.ctrl = cold.ctrl; cc.ep_key = cold.ep_key; cc.ep_ret = cold.ep_ret; cc.ep_cap = cold.ep_cap;
                     cc.stamps = nullptr; cc.tok = nullptr; cc.adv_bitmap = nullptr; cc.pend_list = nullptr;
-                    if (lead && !(cls & 1)) {
-                        cc.s[i] = p.s; cc.a[i] = p.a; cc.pred[i] = p.pred; cc.r[i] = p.r;
-                        cc.term[i] = p.term ? 1 : 0; cc.n[i] = p.n; cc.aux[i] = p.aux;
-                        atomicOr(&cc.inv_bitmap[i >> 5], 1u << (i & 31));
-                        lds.pending[i] = 0;
+                    const bool mine_def = lead && !(cls & 1);
+                    if (c.mode == 0) {
+                        // Sequential learn: the deferred transitions go from their owners' registers
+                        // straight into the ordered path's LDS staging area, at the owner's rank among the
+                        // deferred agents (the ordered path works on an index-sorted list).  The global
+                        // arrays are written too: the path falls back to them when the rows of the
+                        // involved agents do not fit its LDS row cache.
+                        if (mine_def) atomicOr(&lds.def_bits[i >> 5], 1u << (i & 31));
+                        barrier_lds();
+                        if (mine_def) {
+                            int pos = __popc(lds.def_bits[i >> 5] & ((1u << (i & 31)) - 1u));
+                            for (int w = 0; w < (i >> 5); ++w) pos += __popc(lds.def_bits[w]);
+                            lds.slow.a_agent[pos] = i; lds.slow.a_s[pos] = p.s; lds.slow.a_a[pos] = p.a;
+                            lds.slow.a_n[pos] = p.n; lds.slow.a_r[pos] = p.r; lds.slow.a_term[pos] = p.term ? 1 : 0;
+                            cc.inv_list[pos] = i;
+                            cc.s[i] = p.s; cc.a[i] = p.a; cc.pred[i] = p.pred; cc.r[i] = p.r;
+                            cc.term[i] = p.term ? 1 : 0; cc.n[i] = p.n; cc.aux[i] = p.aux;
+                            lds.pending[i] = 0;
+                        }
+                        __syncthreads();
+                        if (tid < PERSIST_MAX_AGENTS / 32) lds.def_bits[tid] = 0u;
+                        slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES, LC>(
+                            cc, ev, FLAG_NO_STAMPS | FLAG_LEARN | FLAG_PRESTAGED, t, n_def, lds.slow);
+                    } else {
+                        if (mine_def) {
+                            cc.s[i] = p.s; cc.a[i] = p.a; cc.pred[i] = p.pred; cc.r[i] = p.r;
+                            cc.term[i] = p.term ? 1 : 0; cc.n[i] = p.n; cc.aux[i] = p.aux;
+                            atomicOr(&cc.inv_bitmap[i >> 5], 1u << (i & 31));
+                            lds.pending[i] = 0;
+                        }
+                        __syncthreads();
+                        (void)build_involved_list(cc, lds.slow.scan);  // == n_def agents
+                        slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES, LC>(cc, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
                     }
-                    __syncthreads();
-                    (void)build_involved_list(cc, lds.slow.scan);  // == n_def agents
-                    slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES, LC>(cc, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
                     __syncthreads();
                 } else {
                     if (tid == 0) lds.n_rem = (unsigned)n_def;
