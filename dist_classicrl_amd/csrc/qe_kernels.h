@@ -392,6 +392,28 @@ __device__ __forceinline__ void ordered_learn(const Ctx<T>& c, const EnvCtx& ev,
     }
 }
 
+// The same for the involved agent staged at list position `pos`: the transition comes from the LDS
+// staging area (nothing is read from the agent arrays), rows and cell from the table.
+template <typename T, class Env, int LC = 0, class Lds>
+__device__ __forceinline__ void ordered_learn_staged(const Ctx<T>& c, const EnvCtx& ev, Lds& lds, int pos, int sub,
+                                                     long long t) {
+    const int64_t i = lds.a_agent[pos];
+    const int32_t s = lds.a_s[pos], a = lds.a_a[pos], n = lds.a_n[pos];
+    const bool term = lds.a_term[pos] != 0;
+    T m = 0;
+    if (!term) {
+        const Row4<T> row = load_row4(c.q, n, c.ld, sub);
+        m = row_max_valid<LC>(row, Env::valid4(ev, i, n, sub), c.L);
+    }
+    if (sub == 0) {
+        const int64_t cell = (int64_t)s * c.ld + a;
+        const T q0 = c.q[cell];
+        T u;
+        c.q[cell] = Td<T>::apply(q0, lds.a_r[pos], m, term, make_hyper(c, c.lr[t]), 0, &u);
+        log_delta(c, t, i, cell, u);
+    }
+}
+
 // Ordered processing of the M involved agents of step t by ONE workgroup (all threads call it).
 // On return their transitions are learned, accounted (FLAG_ACCOUNT), their stamps cleared and --
 // with FLAG_SELECT -- their next transition (select(t+1), env.step(t+1), touches) is pending in the
@@ -752,7 +774,8 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                         ordered_learn_cached<T, Env, LC>(c, ev, lds, pos, sub, t, hyper, cache, is,
                                                      sn >= 0 ? (int)lds.h_row[sn] : is);
                     } else {
-                        ordered_learn<T, Env, LC>(c, ev, list[pos], sub, t);
+                        // rows do not fit the LDS cache: table accesses, transitions still from LDS
+                        ordered_learn_staged<T, Env, LC>(c, ev, lds, pos, sub, t);
                     }
                     if (sub == 0) lds.a_state[pos] = 2;
                 }
@@ -1131,9 +1154,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
                     if (c.mode == 0) {
                         // Sequential learn: the deferred transitions go from their owners' registers
                         // straight into the ordered path's LDS staging area, at the owner's rank among the
-                        // deferred agents (the ordered path works on an index-sorted list).  The global
-                        // arrays are written too: the path falls back to them when the rows of the
-                        // involved agents do not fit its LDS row cache.
+                        // deferred agents (the ordered path works on an index-sorted list); nothing goes
+                        // through the agent arrays in memory.
                         if (mine_def) atomicOr(&lds.def_bits[i >> 5], 1u << (i & 31));
                         barrier_lds();
                         if (mine_def) {
@@ -1141,12 +1163,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
                             for (int w = 0; w < (i >> 5); ++w) pos += __popc(lds.def_bits[w]);
                             lds.slow.a_agent[pos] = i; lds.slow.a_s[pos] = p.s; lds.slow.a_a[pos] = p.a;
                             lds.slow.a_n[pos] = p.n; lds.slow.a_r[pos] = p.r; lds.slow.a_term[pos] = p.term ? 1 : 0;
-                            cc.inv_list[pos] = i;
-                            cc.s[i] = p.s; cc.a[i] = p.a; cc.pred[i] = p.pred; cc.r[i] = p.r;
-                            cc.term[i] = p.term ? 1 : 0; cc.n[i] = p.n; cc.aux[i] = p.aux;
                             lds.pending[i] = 0;
                         }
-                        __syncthreads();
+                        barrier_lds();
                         if (tid < PERSIST_MAX_AGENTS / 32) lds.def_bits[tid] = 0u;
                         slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES, LC>(
                             cc, ev, FLAG_NO_STAMPS | FLAG_LEARN | FLAG_PRESTAGED, t, n_def, lds.slow);
