@@ -1182,18 +1182,17 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
                     }
                     __syncthreads();
                 } else {
-                    if (tid == 0) lds.n_rem = (unsigned)n_def;
-                    __syncthreads();
+                    // lds.n_def itself counts down (every wave has copied it into `n_def` above)
                     bool mine = active && !(cls & 1);
                     if (LC != 1) { pred_s = group_bcast<LC, 0>(pred_s, L); pred_n = group_bcast<LC, 0>(pred_n, L); }
                     int rounds = 0;
-                    while (lds.n_rem > 0u && rounds++ <= n_def) {
+                    while (lds.n_def > 0u && rounds++ <= n_def) {
 #ifdef QE_STAMPS
                         if (tid == 0) c.vinc[18] += 1.0;
 #endif
                         const bool go = mine && (pred_s < 0 || lds.pending[pred_s] == 0) &&
                                         (pred_n < 0 || lds.pending[pred_n] == 0);
-                        __syncthreads();  // everyone has sampled the flags of this round
+                        barrier_lds();  // everyone has sampled the flags of this round
                         if (go) {
                             T m = 0;
                             if (!p.term) {
@@ -1207,13 +1206,13 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
                                 c.q[cell] = Td<T>::apply(q0, p.r, m, p.term, make_hyper(c, c.lr[t]), 0, &u);
                                 log_delta(c, t, i, cell, u);
                                 lds.pending[i] = 0;
-                                atomicSub(&lds.n_rem, 1u);
+                                atomicSub(&lds.n_def, 1u);
                             }
                             mine = false;
                         }
                         __syncthreads();  // this round's table writes are complete and visible
                     }
-                    if (tid == 0 && lds.n_rem > 0u) reinterpret_cast<const Ctx<T>*>(lds.cold)->ctrl->error = 2u;
+                    if (tid == 0 && lds.n_def > 0u) reinterpret_cast<const Ctx<T>*>(lds.cold)->ctrl->error = 2u;
                 }
             }
             // every update of step t is in the table: late selections read their row again
