@@ -456,9 +456,12 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             // up to 512 threads the kernel is built with twice the vector-register budget (the BASELINE
             // shapes with 128 agents: 256 or 512 lanes)
             constexpr int SMALL = (LCV == 2 || LCV == 4) ? 512 : 1024;
-            const bool lean = mode == QE_LEARN_ITER && !c.trace && !c.dlog;
-            if ((LCV == 2 || LCV == 4) && block <= 512 && lean)
-                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL, SMALL == 512>), dim3(1),
+            const bool lean = mode == QE_LEARN_ITER && !c.trace;
+            if ((LCV == 2 || LCV == 4) && block <= 512 && lean && !c.dlog)
+                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL, SMALL == 512 ? 1 : 0>), dim3(1),
+                                   dim3(block), 0, e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+            else if ((LCV == 2 || LCV == 4) && block <= 512 && lean)
+                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL, SMALL == 512 ? 2 : 0>), dim3(1),
                                    dim3(block), 0, e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if ((LCV == 2 || LCV == 4) && block <= 512)
                 hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL>), dim3(1),

@@ -912,10 +912,11 @@ __device__ __forceinline__ int ct_insert(PersistLds& l, int tb, int32_t row, uns
 // LEAN = the launch is known to be a plain training rollout (sequential `learn`, no action trace, no
 // delta log): the compiler is told so, which removes three families of uniform branches and their
 // operands from the scalar-register budget of the loop.
-template <typename T, class Env, int LC, int BLOCK = 1024, bool LEAN = false>
+template <typename T, class Env, int LC, int BLOCK = 1024, int LEAN = 0>
 __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx ev, long long steps, int flags) {
     __shared__ PersistLds lds;
-    if constexpr (LEAN) { c.mode = 0; c.trace = nullptr; c.dlog = nullptr; }
+    if constexpr (LEAN != 0) { c.mode = 0; c.trace = nullptr; }
+    if constexpr (LEAN == 1) c.dlog = nullptr;
 #ifdef QE_STAMPS
     long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long stamp_last = wall_clock64();
@@ -966,8 +967,11 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
     }
     __syncthreads();
     int tb = 0;  // t % 3
+    DeltaEntry* dl = c.dlog ? c.dlog + c.dlog_base + ii : nullptr;  // this agent's record of step 0
+    const long long dl_steps = c.dlog ? (c.dlog_cap - c.dlog_base) / c.N : 0;  // steps whose records all fit
     for (long long t = 0; t < steps; ++t) {
         const bool last = t + 1 == steps;
+        const bool dl_ok = t < dl_steps;
         const int tb_old = tb == 2 ? 0 : tb + 1;  // (t - 2) % 3 == (t + 1) % 3: retired two barriers ago
         QE_STAMP(7);
         // ---- register this step's touches (W(s), R(n)); retire the entries of step t-2 ---------
@@ -1090,7 +1094,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
             const T q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, c.lr[t]), c.mode, &u);
             if (sub == 0) {
                 c.q[cell] = q1;
-                log_delta(c, t, i, cell, u);
+                // delta log of the replica exchange: a running pointer instead of log_delta's 64-bit
+                // slot arithmetic (slot = base + t * N + agent)
+                if (dl_ok) *dl = DeltaEntry{(uint32_t)cell, (float)u};
             }
             if (p.n == p.s && (p.a >> 2) == sub) {
                 const int j = p.a & 3;
@@ -1243,6 +1249,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
             if (tid == 0) lds.ep_n = 0u;
         }
         tb = tb == 2 ? 0 : tb + 1;
+        if (c.dlog) dl += c.N;
         QE_STAMP(6);
     }
 #ifdef QE_STAMPS
