@@ -43,6 +43,7 @@ constexpr int FLAG_PRED_FROM_TABLE = 8;  // qe_learn: Q[s,a] is not carried, rea
 constexpr int FLAG_ACCOUNT = 16;         // episode-return bookkeeping (rollouts; not qe_learn)
 constexpr int FLAG_NO_STAMPS = 32;       // persistent kernel: contention is tracked in LDS instead
 constexpr int FLAG_T_MINUS_1 = 64;       // the step counter has already been advanced (k_advance)
+constexpr int FLAG_LIST_IN_LDS = 512;    // ordered path: the involved list (<= CAP entries) is mirrored in its LDS a_agent[]
 constexpr int FLAG_PRESTAGED = 256;      // ordered path: the caller has staged the transitions in LDS (persistent kernel)
 constexpr int FLAG_VEC_INC_READY = 128;  // VEC, wide mode: the increments of the involved agents are already in vinc
 constexpr uint32_t TOK_INF = 0xFFFFFFFFu;
@@ -453,7 +454,7 @@ __device__ __forceinline__ void ordered_learn_cached(const Ctx<T>& c, const EnvC
 // Ordered list of the involved agents (ascending agent index) from the bitmap, which is cleared on
 // the way; every thread of the workgroup calls it and gets the count.
 template <typename T>
-__device__ int build_involved_list(const Ctx<T>& c, int* scan) {
+__device__ int build_involved_list(const Ctx<T>& c, int* scan, int* mirror = nullptr, int mirror_cap = 0) {
     const int tid = threadIdx.x, BS = (int)blockDim.x;
     const int W = (int)((c.N + 31) >> 5);
     int base = 0;
@@ -464,6 +465,7 @@ __device__ int build_involved_list(const Ctx<T>& c, int* scan) {
         int p = base + block_excl_scan(__popc(word), &total, scan);
         while (word) {
             const int b = __ffs(word) - 1;
+            if (p < mirror_cap) mirror[p] = w * 32 + b;  // LDS copy: the ordered path need not re-read memory
             c.inv_list[p++] = w * 32 + b;
             word &= word - 1u;
         }
@@ -572,7 +574,7 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                 i = lds.a_agent[pos];
                 g.s = lds.a_s[pos]; g.a = lds.a_a[pos]; g.n = lds.a_n[pos]; g.r = lds.a_r[pos]; g.term = lds.a_term[pos] != 0;
             } else {
-                i = list[pos];
+                i = (flags & FLAG_LIST_IN_LDS) ? (int64_t)lds.a_agent[pos] : (int64_t)list[pos];
                 g = live_agent(c, i);
             }
             const bool need = (id & 1) == 0 || !g.term;  // id even: W(row s); odd: R(row n), unless terminated
@@ -802,9 +804,18 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
     // ---- bookkeeping, stamp clean-up, then select(t+1) + env.step(t+1) for involved agents -----
     const int par = (int)(t & 1);
     const bool tail_work = (flags & FLAG_ACCOUNT) || !(flags & FLAG_NO_STAMPS) || c.tok != nullptr;
+    // one batch in sequential mode: everything about the involved agents is still staged in LDS
+    const bool staged = c.mode == 0 && M_all <= CAP;
     for (int pos = tid; pos < (tail_work ? M : 0); pos += BS) {
-        const int64_t i = c.inv_list[pos];
-        const LiveAgent<T> g = live_agent(c, i);
+        int64_t i;
+        LiveAgent<T> g;
+        if (staged) {
+            i = lds.a_agent[pos];
+            g.s = lds.a_s[pos]; g.a = lds.a_a[pos]; g.n = lds.a_n[pos]; g.r = lds.a_r[pos]; g.term = lds.a_term[pos] != 0;
+        } else {
+            i = c.inv_list[pos];
+            g = live_agent(c, i);
+        }
         if (flags & FLAG_ACCOUNT) account(c, t, i, g.r, g.term);
         if (!(flags & FLAG_NO_STAMPS)) {
             c.stamps[2 * (int64_t)g.s + par] = 0ull;
@@ -820,8 +831,8 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
         for (int p0 = 0; p0 < M; p0 += ngrp) {
             const int pos = p0 + grp;
             if (pos < M) {
-                const int64_t i = c.inv_list[pos];
-                const int32_t n = c.n[i];
+                const int64_t i = staged ? (int64_t)lds.a_agent[pos] : (int64_t)c.inv_list[pos];
+                const int32_t n = staged ? lds.a_n[pos] : c.n[i];
                 Row4<T> row = load_row4(c.q, n, c.ld, sub);
                 advance_agent<T, Env, LC>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t + 1, flags);
             }
@@ -837,7 +848,8 @@ __global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, i
     __shared__ SlowLds lds;
     const long long t = c.ctrl->t_local;
     int M = 0;
-    if (c.ctrl->inv_count != 0u && (flags & FLAG_LEARN)) M = build_involved_list(c, lds.scan);
+    if (c.ctrl->inv_count != 0u && (flags & FLAG_LEARN)) M = build_involved_list(c, lds.scan, lds.a_agent, SLOW_CAP);
+    if (M <= SLOW_CAP) flags |= FLAG_LIST_IN_LDS;
 #ifdef QE_STAMPS
     if (t == 0 && threadIdx.x == 0 && c.vinc) for (int k = 0; k < 24; ++k) c.vinc[k] = 0.0;
     __syncthreads();
