@@ -210,6 +210,7 @@ struct qe_engine {
     unsigned timing_skip = 0;      // launches since the engine was created (timed-launch cadence)
     double ms_per_step_est = 0.0;  // device time per step of the last timed launch
     hipEvent_t plan_ready = nullptr;
+    PinnedBuf<uint8_t> h_stage;         // page-locked staging of the unfused batch API (one call at a time)
     hipStream_t copy_stream = nullptr;  // result read-back beside the compute stream
     RolloutSlot slots[2];               // two rollouts may be in flight (begin k+1 before end k)
     size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
@@ -748,6 +749,7 @@ int qe_destroy(qe_engine* e) {
     e->slots[0].release(); e->slots[1].release();
     if (e->plan_ready) (void)hipEventDestroy(e->plan_ready);
     e->plan_thr.release(); e->plan_lr.release(); e->h_plan_thr.release(); e->h_plan_lr.release();
+    e->h_stage.release();
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     e->thr.release(); e->lr.release(); e->b_s.release(); e->b_a.release(); e->b_n.release();
     e->b_out.release(); e->b_list.release(); e->b_r.release(); e->b_acc.release(); e->b_term.release();
@@ -849,6 +851,24 @@ uint64_t qe_get_step_counter(qe_engine* e) { return e->step_ctr; }
 int qe_set_agent_offset(qe_engine* e, uint32_t off) { e->agent_offset = off; return QE_OK; }
 
 // ---- selection -------------------------------------------------------------------------------
+// Host -> device through the engine's page-locked staging area: pageable sources make every
+// hipMemcpyAsync a blocking staged copy (~10 us each); from pinned memory they only enqueue.
+struct Stager {
+    qe_engine* e;
+    size_t off = 0;
+    int reserve(size_t bytes) {
+        HIP_TRY(e->h_stage.ensure(bytes));
+        return QE_OK;
+    }
+    int push(void* dst, const void* src, size_t bytes) {
+        uint8_t* at = e->h_stage.p + off;
+        memcpy(at, src, bytes);
+        off += (bytes + 15) & ~(size_t)15;
+        HIP_TRY(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, e->stream));
+        return QE_OK;
+    }
+};
+
 int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint8_t* masks, double eps,
                       int32_t deterministic, int32_t* out) {
     if (n < 0 || (n > 0 && (!states || !out))) return fail(QE_ERR_INVALID, "bad argument");
@@ -856,13 +876,16 @@ int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint
     if (int rc = check_indices(states, n, e->S, "states")) return rc;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(e->b_s.ensure((size_t)n)); HIP_TRY(e->b_out.ensure((size_t)n));
-    HIP_TRY(hipMemcpyAsync(e->b_s.p, states, n * 4, hipMemcpyHostToDevice, e->stream));
     std::vector<uint32_t> packed;
     if (masks) {
         pack_masks(masks, n, e->A, packed);
         HIP_TRY(e->b_mask.ensure(packed.size()));
-        HIP_TRY(hipMemcpyAsync(e->b_mask.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, e->stream));
     }
+    Stager up{e};
+    if (int rc = up.reserve((size_t)n * 8 + packed.size() * 4 + 64)) return rc;
+    if (int rc = up.push(e->b_s.p, states, (size_t)n * 4)) return rc;
+    if (masks) if (int rc = up.push(e->b_mask.p, packed.data(), packed.size() * 4)) return rc;
+    int32_t* out_stage = reinterpret_cast<int32_t*>(e->h_stage.p + up.off);  // results land in pinned memory too
     const EnvCtx ev = make_envctx(e, nullptr, e->b_mask.p, masks ? 1 : 0);
     const unsigned long long thr = eps_threshold(eps);
     const bool large = e->ld > 256;
@@ -877,9 +900,10 @@ int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint
                                e->stream, c, ev, e->b_s.p, thr, deterministic, e->b_out.p);
     };
     if (e->dtype == QE_F32) go(float{}); else go(double{});
-    HIP_TRY(hipMemcpyAsync(out, e->b_out.p, n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(out_stage, e->b_out.p, n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
+    memcpy(out, out_stage, (size_t)n * 4);
     e->step_ctr += 1;
     return QE_OK;
 }
@@ -901,11 +925,16 @@ static int learn_buffers(qe_engine* e, int64_t n) {
 }
 
 // Runs the update kernels over the n transitions already sitting in the batch buffers and waits.
-static int learn_launch(qe_engine* e, int64_t n, double lr, bool masked, int32_t mode) {
+static int learn_launch(qe_engine* e, int64_t n, double lr, bool masked, int32_t mode, Stager* up = nullptr) {
     const unsigned long long thr0 = 0;
     HIP_TRY(e->thr.ensure(1)); HIP_TRY(e->lr.ensure(1));
-    HIP_TRY(hipMemcpyAsync(e->thr.p, &thr0, 8, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->lr.p, &lr, 8, hipMemcpyHostToDevice, e->stream));
+    if (up) {  // through the pinned staging area (room was reserved by the caller)
+        if (int rc = up->push(e->thr.p, &thr0, 8)) return rc;
+        if (int rc = up->push(e->lr.p, &lr, 8)) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(e->thr.p, &thr0, 8, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->lr.p, &lr, 8, hipMemcpyHostToDevice, e->stream));
+    }
     HIP_TRY(hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream));
     const EnvCtx ev = make_envctx(e, nullptr, e->b_mask.p, masked ? 1 : 0);
     const bool large = e->ld > 256;
@@ -950,18 +979,20 @@ int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const 
     }
     HIP_TRY(hipSetDevice(e->device));
     if (int rc = learn_buffers(e, n)) return rc;
-    HIP_TRY(hipMemcpyAsync(e->b_s.p, states, n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->b_a.p, actions, n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->b_n.p, nxt.data(), n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->b_r.p, rewards, n * 4, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->b_term.p, terminated, n, hipMemcpyHostToDevice, e->stream));
     std::vector<uint32_t> packed;
     if (next_masks) {
         pack_masks(next_masks, n, e->A, packed);
         HIP_TRY(e->b_mask.ensure(packed.size()));
-        HIP_TRY(hipMemcpyAsync(e->b_mask.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, e->stream));
     }
-    return learn_launch(e, n, lr, next_masks != nullptr, mode);
+    Stager up{e};
+    if (int rc = up.reserve((size_t)n * 17 + packed.size() * 4 + 256)) return rc;
+    if (int rc = up.push(e->b_s.p, states, (size_t)n * 4)) return rc;
+    if (int rc = up.push(e->b_a.p, actions, (size_t)n * 4)) return rc;
+    if (int rc = up.push(e->b_n.p, nxt.data(), (size_t)n * 4)) return rc;
+    if (int rc = up.push(e->b_r.p, rewards, (size_t)n * 4)) return rc;
+    if (int rc = up.push(e->b_term.p, terminated, (size_t)n)) return rc;
+    if (next_masks) if (int rc = up.push(e->b_mask.p, packed.data(), packed.size() * 4)) return rc;
+    return learn_launch(e, n, lr, next_masks != nullptr, mode, &up);
 }
 
 // ---- environments ------------------------------------------------------------------------------
