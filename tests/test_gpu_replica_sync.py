@@ -68,8 +68,8 @@ def test_bench_under_the_distributed_launcher_env():
                MASTER_PORT=str(_free_port()))
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1500", "--warmup", "200",
                           "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600, check=True)
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{")  # nothing but the JSON line on stdout (RCCL banner -> stderr)
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["steps"] == 1500 and line["scaling"] == "weak"
     assert line["config"]["sync_every"] == 100 and line["value"] > 1e6
