@@ -552,12 +552,14 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
                 store_live(c.q + cell, q);
             }
         }
-    } else for (int base = 0; base < M_all; base += CAP) {
+    } else for (int base = 0, B = (M_all > CAP ? min(CAP, ngrp) : CAP); base < M_all; base += B) {
         // ---- ITER: dataflow rounds; per shared row, touchers run in agent order ---------------
-        // More involved agents than the LDS structures hold are taken in batches of CAP in agent
-        // order: every dependency points from a lower to a higher agent index, so a batch only
-        // needs the batches before it to be complete (their cells are in the table by then).
-        const int M = min(CAP, M_all - base);
+        // More involved agents than the LDS structures hold are taken in batches in agent order: every
+        // dependency points from a lower to a higher agent index, so a batch only needs the batches
+        // before it to be complete (their cells are in the table by then).  The batches are sized for
+        // the register-resident rounds (one lane group per agent), whose run-ahead compresses the long
+        // same-cell chains that make such steps large in the first place.
+        const int M = min(B, M_all - base);
         const int32_t* list = c.inv_list + base;
         if (base) __syncthreads();
         for (int k = tid; k < HASH; k += BS) { lds.h_key[k] = -1; lds.h_head[k] = -1; lds.h_done[k] = 0; }
