@@ -196,7 +196,7 @@ def main() -> None:
     persistent = stats["launches"] < args.steps
     traffic = None  # HBM bytes per launch from the PMC passes kept under profiles/ (same kernel, same workload)
     try:
-        prof = json.loads((ROOT / "profiles" / "r01g_traffic.json").read_text()).get(args.workload)
+        prof = json.loads((ROOT / "profiles" / "r01h_traffic.json").read_text()).get(args.workload)
         if prof and persistent and "persistent" in prof["kernel"]:
             traffic = prof["traffic_bytes_per_env_step"] * units_per_launch
     except (OSError, ValueError, KeyError):

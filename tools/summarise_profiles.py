@@ -51,7 +51,7 @@ out = {
     "headline": {
         "command": "rocprofv3 --kernel-trace --pmc <counter group> --output-format csv -- python3 bench.py --steps 20000 "
                    "--warmup 2000 --no-cpu-baseline (one pass per group: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)",
-        "kernel": "k_rollout_persistent<float, HashEnv, 4, 512, true>",
+        "kernel": "k_rollout_persistent<float, HashEnv, 4, 512, 1>",
         "launches": n1,
         "env_steps_all_launches": env_steps,
         "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
