@@ -78,33 +78,42 @@ def _worker(rank, world, port, out_dir, overlap, one_launch=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize(("overlap", "one_launch"), [(False, False), (True, False), (True, True)])
-def test_two_rank_replica_sync_matches_single_process_simulation(tmp_path, overlap, one_launch):
+@pytest.mark.parametrize(("world", "overlap", "one_launch"),
+                         [(2, False, False), (2, True, False), (2, True, True), (3, True, True), (3, False, False)])
+def test_replica_sync_matches_single_process_simulation(tmp_path, world, overlap, one_launch):
     from oracle import c_oracle
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path), overlap, one_launch), nprocs=2, join=True)
-    q0, q1 = np.load(tmp_path / "q0.npy"), np.load(tmp_path / "q1.npy")
+    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap, one_launch), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"q{r}.npy") for r in range(world)]
 
-    # single-process simulation of the same protocol: without overlap the other rank's records are
-    # applied at the sync point, with overlap one chunk later (and at the final flush)
-    runs = [c_oracle.CHashRollout(N_PER_RANK, S, A, agent_offset=r * N_PER_RANK, dtype=np.float32) for r in (0, 1)]
+    # single-process simulation of the same protocol: without overlap the other ranks' records are
+    # applied at the sync point (in rank order), with overlap one chunk later (and at the final flush)
+    runs = [c_oracle.CHashRollout(N_PER_RANK, S, A, agent_offset=r * N_PER_RANK, dtype=np.float32)
+            for r in range(world)]
+
+    def apply_others(recs):
+        for me in range(world):
+            for other in range(world):
+                if other != me:
+                    _apply(runs[me].q, *recs[other])
+
     late = None
     for k in range(CHUNKS):
         recs = [_run_chunk(run, k) for run in runs]
         ready = late if overlap else recs
         if ready is not None:
-            _apply(runs[0].q, *ready[1])
-            _apply(runs[1].q, *ready[0])
+            apply_others(ready)
         late = recs
     if overlap:
-        _apply(runs[0].q, *late[1])
-        _apply(runs[1].q, *late[0])
-    assert np.array_equal(q0, runs[0].q) and np.array_equal(q1, runs[1].q)
-    assert np.count_nonzero(q0) > 100
-    assert np.allclose(q0, q1, rtol=1e-5, atol=1e-6)  # same sums, different fp32 summation order
+        apply_others(late)
+    for r in range(world):
+        assert np.array_equal(got[r], runs[r].q), r
+    assert np.count_nonzero(got[0]) > 100
+    for r in range(1, world):
+        assert np.allclose(got[0], got[r], rtol=1e-5, atol=1e-6)  # same sums, different fp32 summation order
     assert not np.array_equal(np.load(tmp_path / "obs0.npy"), np.load(tmp_path / "obs1.npy"))
 
 
