@@ -127,6 +127,11 @@ def main() -> None:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {n_gpus} rank(s) were started; launch N > 1 with\n"
+                         f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port P bench.py --gpus {args.gpus} ...\n")
+        raise SystemExit(2)
 
     from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
     from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
