@@ -275,16 +275,23 @@ unsigned long long eps_threshold(double eps) {
     return v >= 4294967296.0 ? (1ull << 32) : (unsigned long long)v;
 }
 
+static int slot_create(qe_engine* e, RolloutSlot& sl) {
+    if (sl.ctrl) return QE_OK;
+    HIP_TRY(hipMalloc((void**)&sl.ctrl, sizeof(Ctrl)));
+    HIP_TRY(hipEventCreate(&sl.ev0));
+    HIP_TRY(hipEventCreate(&sl.ev1));
+    HIP_TRY(hipEventCreateWithFlags(&sl.sched_ready, hipEventDisableTiming));
+    HIP_TRY(sl.ep_key.ensure((size_t)e->ep_cap));
+    HIP_TRY(sl.ep_ret.ensure((size_t)e->ep_cap));
+    HIP_TRY(sl.h_ctrl.ensure(1));
+    return QE_OK;
+}
+
 int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps, const double* lr, bool use_plan) {
-    if (!sl.ctrl) {
-        HIP_TRY(hipMalloc((void**)&sl.ctrl, sizeof(Ctrl)));
-        HIP_TRY(hipEventCreate(&sl.ev0));
-        HIP_TRY(hipEventCreate(&sl.ev1));
-        HIP_TRY(hipEventCreateWithFlags(&sl.sched_ready, hipEventDisableTiming));
-        HIP_TRY(sl.ep_key.ensure((size_t)e->ep_cap));
-        HIP_TRY(sl.ep_ret.ensure((size_t)e->ep_cap));
-        HIP_TRY(sl.h_ctrl.ensure(1));
-    }
+    // both result slots are set up at the first rollout: a later, longer call that pipelines through the
+    // second slot does not pay for allocations then
+    for (RolloutSlot& each : e->slots)
+        if (int rc = slot_create(e, each)) return rc;
     sl.plan_offset = -1;
     if (use_plan) {  // the values are already on the device
         sl.plan_offset = e->plan_cursor;
@@ -595,8 +602,17 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
     }
     e->ep_host.resize((size_t)got);
     if (got) {
-        HIP_TRY(sl.h_key.ensure((size_t)got));
-        HIP_TRY(sl.h_ret.ensure((size_t)got));
+        // page-locked staging grows in big strides (re-allocating it costs milliseconds, and a timed call
+        // usually finishes several times the episodes of its warm-up)
+        if ((size_t)got > sl.h_key.cap || (size_t)got > sl.h_ret.cap) {
+            const size_t want = std::min<size_t>((size_t)e->ep_cap, std::max<size_t>((size_t)got * 4, (size_t)1 << 16));
+            // both slots (see slot_prepare); the other slot's staging is idle even while its rollout is in
+            // flight: only its own qe_rollout_end copies into it
+            for (RolloutSlot& each : e->slots) {
+                HIP_TRY(each.h_key.ensure(want));
+                HIP_TRY(each.h_ret.ensure(want));
+            }
+        }
         if (sl.persistent) {
             HIP_TRY(hipMemcpyAsync(sl.h_key.p, sl.ep_key.p, got * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->copy_stream));
             HIP_TRY(hipMemcpyAsync(sl.h_ret.p, sl.ep_ret.p, got * sizeof(float), hipMemcpyDeviceToHost, e->copy_stream));
@@ -726,6 +742,19 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     if (err == hipSuccess) err = hipMemsetAsync(e->stamps, 0, (size_t)S * 2 * sizeof(unsigned long long), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    // The HIP runtime sets its copy paths up on first use, per direction and size class: the first
+    // device-to-pinned copy of a few tens of KB was measured at 7.6 ms (27 us afterwards).  Touch
+    // them here so that the first long rollout does not pay for it.
+    if (err == hipSuccess && bytes >= ((size_t)1 << 20)) {
+        err = e->h_stage.ensure((size_t)1 << 20);
+        for (size_t sz : {(size_t)4 << 10, (size_t)64 << 10, (size_t)1 << 20}) {
+            for (hipStream_t st : {e->copy_stream, e->stream}) {
+                if (err == hipSuccess) err = hipMemcpyAsync(e->h_stage.p, e->q, sz, hipMemcpyDeviceToHost, st);
+                if (err == hipSuccess) err = hipMemcpyAsync(e->q, e->h_stage.p, sz, hipMemcpyHostToDevice, st);
+                if (err == hipSuccess) err = hipStreamSynchronize(st);  // (the table is all zeros: a round trip leaves it so)
+            }
+        }
+    }
     if (err != hipSuccess) {
         int code = fail(err == hipErrorOutOfMemory ? QE_ERR_OOM : QE_ERR_NO_DEVICE,
                         "engine allocation failed: %s", hipGetErrorString(err));
