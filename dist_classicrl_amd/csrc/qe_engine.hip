@@ -211,6 +211,7 @@ struct qe_engine {
     double ms_per_step_est = 0.0;  // device time per step of the last timed launch
     hipEvent_t plan_ready = nullptr;
     PinnedBuf<uint8_t> h_stage;         // page-locked staging of the unfused batch API (one call at a time)
+    DevBuf<uint8_t> warm_scratch;       // 1 MB of device memory for warm_pinned()
     hipStream_t copy_stream = nullptr;  // result read-back beside the compute stream
     RolloutSlot slots[2];               // two rollouts may be in flight (begin k+1 before end k)
     size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
@@ -273,6 +274,23 @@ unsigned long long eps_threshold(double eps) {
     if (eps >= 1.0) return 1ull << 32;
     const double v = std::ceil(eps * 4294967296.0);
     return v >= 4294967296.0 ? (1ull << 32) : (unsigned long long)v;
+}
+
+// A freshly page-locked buffer costs ~8 ms on its first DMA of more than a few KB (the runtime maps it
+// for the copy engine lazily; measured: 7.6 ms, then 27 us).  Pay that when the buffer is allocated --
+// engine start-up or a growth step -- not in the middle of somebody's first long rollout: one copy in
+// each direction over the whole buffer, against device scratch.
+static int warm_pinned(qe_engine* e, void* host, size_t bytes) {
+    constexpr size_t CHUNK = (size_t)1 << 20;
+    if (!host || bytes == 0) return QE_OK;
+    HIP_TRY(e->warm_scratch.ensure(CHUNK));
+    for (size_t off = 0; off < bytes; off += CHUNK) {
+        const size_t len = std::min(CHUNK, bytes - off);
+        HIP_TRY(hipMemcpyAsync((uint8_t*)host + off, e->warm_scratch.p, len, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipMemcpyAsync(e->warm_scratch.p, (uint8_t*)host + off, len, hipMemcpyHostToDevice, e->copy_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    return QE_OK;
 }
 
 static int slot_create(qe_engine* e, RolloutSlot& sl) {
@@ -609,8 +627,11 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
             // both slots (see slot_prepare); the other slot's staging is idle even while its rollout is in
             // flight: only its own qe_rollout_end copies into it
             for (RolloutSlot& each : e->slots) {
+                if (want <= each.h_key.cap && want <= each.h_ret.cap) continue;
                 HIP_TRY(each.h_key.ensure(want));
                 HIP_TRY(each.h_ret.ensure(want));
+                if (int rc = warm_pinned(e, each.h_key.p, each.h_key.cap * 8)) return rc;
+                if (int rc = warm_pinned(e, each.h_ret.p, each.h_ret.cap * 4)) return rc;
             }
         }
         if (sl.persistent) {
@@ -747,7 +768,10 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     // them here so that the first long rollout does not pay for it.
     if (err == hipSuccess && bytes >= ((size_t)1 << 20)) {
         err = e->h_stage.ensure((size_t)1 << 20);
-        for (size_t sz : {(size_t)4 << 10, (size_t)64 << 10, (size_t)1 << 20}) {
+        // (sizes of several classes and alignments: the runtime picks among copy-kernel variants by
+        // both, and loads each variant on first use)
+        for (size_t sz : {(size_t)8, (size_t)1000, (size_t)4 << 10, (size_t)12000, (size_t)24000, (size_t)64 << 10,
+                          (size_t)100000, (size_t)256 << 10, (size_t)1 << 20}) {
             for (hipStream_t st : {e->copy_stream, e->stream}) {
                 if (err == hipSuccess) err = hipMemcpyAsync(e->h_stage.p, e->q, sz, hipMemcpyDeviceToHost, st);
                 if (err == hipSuccess) err = hipMemcpyAsync(e->q, e->h_stage.p, sz, hipMemcpyHostToDevice, st);
@@ -778,7 +802,7 @@ int qe_destroy(qe_engine* e) {
     e->slots[0].release(); e->slots[1].release();
     if (e->plan_ready) (void)hipEventDestroy(e->plan_ready);
     e->plan_thr.release(); e->plan_lr.release(); e->h_plan_thr.release(); e->h_plan_lr.release();
-    e->h_stage.release();
+    e->h_stage.release(); e->warm_scratch.release();
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     e->thr.release(); e->lr.release(); e->b_s.release(); e->b_a.release(); e->b_n.release();
     e->b_out.release(); e->b_list.release(); e->b_r.release(); e->b_acc.release(); e->b_term.release();
@@ -1203,8 +1227,18 @@ int qe_schedule_plan(qe_engine* e, const double* eps, const double* lr, int64_t 
     // sized generously and doubled when outgrown: re-allocating pinned memory costs milliseconds
     size_t cap = std::max<size_t>(e->plan_thr.cap, (size_t)1 << 16);
     while (cap < (size_t)count) cap *= 2;
-    HIP_TRY(e->h_plan_thr.ensure(cap)); HIP_TRY(e->h_plan_lr.ensure(cap));
-    HIP_TRY(e->plan_thr.ensure(cap)); HIP_TRY(e->plan_lr.ensure(cap));
+    if (cap > e->h_plan_thr.cap) {
+        HIP_TRY(e->h_plan_thr.ensure(cap)); HIP_TRY(e->h_plan_lr.ensure(cap));
+        if (int rc = warm_pinned(e, e->h_plan_thr.p, e->h_plan_thr.cap * 8)) return rc;
+        if (int rc = warm_pinned(e, e->h_plan_lr.p, e->h_plan_lr.cap * 8)) return rc;
+    }
+    if (cap > e->plan_thr.cap) {
+        HIP_TRY(e->plan_thr.ensure(cap)); HIP_TRY(e->plan_lr.ensure(cap));
+        // ... and the exact pair used below, over the whole new capacity
+        HIP_TRY(hipMemcpyAsync(e->plan_thr.p, e->h_plan_thr.p, cap * 8, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(hipMemcpyAsync(e->plan_lr.p, e->h_plan_lr.p, cap * 8, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    }
     for (int64_t t = 0; t < count; ++t) e->h_plan_thr.p[t] = eps_threshold(eps[t]);
     memcpy(e->h_plan_lr.p, lr, (size_t)count * sizeof(double));
     if (!e->plan_ready) HIP_TRY(hipEventCreateWithFlags(&e->plan_ready, hipEventDisableTiming));
