@@ -172,8 +172,7 @@ def main() -> None:
         try:
             return rt.run_steps(steps, env, state)[3]
         except ZeroDivisionError:
-            states, rewards = env.observe()
-            return {"states": states, "infos": [{}] * n, "rewards": rewards, "episode_rewards": []}
+            return env.state_dict()
 
     sd = run_steps(max(1, args.warmup), None)  # untimed warm-up (also resets the env)
     sync_all()

@@ -24,6 +24,8 @@ OPT_ROLLOUT_PATH = 0
 OPT_USE_GRAPH = 1
 OPT_TOKEN_ROUNDS = 2
 OPT_LISTED_MIN_AGENTS = 3
+OPT_EVENT_TIMING = 4
+OPT_HOST_BLOCK = 5
 PATH_AUTO, PATH_STEPWISE, PATH_PERSISTENT, PATH_WIDE = 0, 1, 2, 3
 
 ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INDEX = -1, -2, -3, -4, -5
@@ -56,6 +58,7 @@ class RolloutStats(C.Structure):
         ("dominant_ms", C.c_double),
         ("dominant_launches", C.c_int64),
         ("dominant_env_steps", C.c_int64),
+        ("device_clock_ms", C.c_double),
     ]
 
 
@@ -97,6 +100,7 @@ PROTOTYPES = {
     "qe_rollout_begin": (C.c_int, [_P, _P, C.c_int64, _F64P, _F64P, C.c_int32, C.c_int32]),
     "qe_schedule_plan": (C.c_int, [_P, _F64P, _F64P, C.c_int64]),
     "qe_rollout_end": (C.c_int, [_P, C.c_int32, C.POINTER(RolloutStats)]),
+    "qe_rollout_chunk_limit": (C.c_int64, [_P, _P, C.c_int32]),
     "qe_evaluate": (C.c_int, [_P, _P, C.c_int64, C.POINTER(RolloutStats)]),
     "qe_episode_log": (C.c_int64, [_P, C.c_int64, _I32P, _I32P, _F32P]),
     "qe_delta_log_attach": (C.c_int, [_P, _P, C.c_int64]),

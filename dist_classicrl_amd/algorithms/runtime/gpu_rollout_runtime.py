@@ -20,10 +20,19 @@ from dist_classicrl_amd.environments.device_envs import DeviceVecEnv
 
 from .base_runtime import BaseRuntime, _count_agents
 
-_EP_LOG_CAPACITY = 1 << 22  # entries held by the engine's episode log (csrc/qe_engine.hip)
+_SHORT_CALL = 64  # up to here the schedule values are produced by a plain Python loop (no NumPy set-up cost)
 
 
 def _schedule_values(schedule, n_updates, count):
+    """The ``count`` values ``get_value(); update(n_updates); ...`` reads, as a ctypes double array
+    (short calls) or a float64 ndarray; the schedule is left advanced (base_runtime.py:248,262-263)."""
+    if count <= _SHORT_CALL:
+        out = (C.c_double * count)()
+        get, update = schedule.get_value, schedule.update
+        for t in range(count):
+            out[t] = get()
+            update(n_updates)
+        return out
     fast = getattr(schedule, "advance_values", None)
     if fast is not None:
         return np.ascontiguousarray(fast(n_updates, count), dtype=np.float64)
@@ -32,6 +41,12 @@ def _schedule_values(schedule, n_updates, count):
         out[t] = schedule.get_value()
         schedule.update(n_updates)
     return out
+
+
+def _f64_ptr(values):
+    if isinstance(values, np.ndarray):
+        return _lib.ptr(values, C.c_double)
+    return C.cast(values, C.POINTER(C.c_double))
 
 
 def _sequential_sum(values: np.ndarray):
@@ -52,7 +67,10 @@ class GpuRolloutQLearning(BaseRuntime):
         self.last_stats = None  # accumulated qe_rollout_stats of the latest run_steps call
         self.delta_sync = None  # dist_classicrl_amd.distributed.DeltaSync (multi-GPU replicas)
         self.sync_every = 100
-        self.trace_actions = None  # set to True to collect every action (tests)
+        # set to True to collect every action of the following run_steps calls (tests); the (steps, n)
+        # array of the latest call is left in `last_trace` (and, for older callers, here)
+        self.trace_actions = None
+        self.last_trace = None
         # element type of the reward history `run_steps` returns: "float" (list of Python floats, the
         # float32 returns widened exactly), "float32" (list of numpy.float32 scalars, the reference's
         # element type, ~2x slower to build) or "array" (the float32 array itself: no per-episode
@@ -79,13 +97,19 @@ class GpuRolloutQLearning(BaseRuntime):
     _PIPELINE_CHUNK = 2000  # vector steps per launch when nothing else (log capacity, sync cadence) binds
 
     def _collect(self, lib, algo, st, done, total, history, ep_steps):
-        cnt = int(lib.qe_episode_log(algo.handle, 0, None, None, None))
+        if st.episodes_dropped:
+            # cannot happen with chunks sized by qe_rollout_chunk_limit; never lose returns silently
+            msg = f"episode log overflow: {st.episodes_dropped} episode returns were dropped"
+            raise _lib.EngineError(msg)
+        cnt = int(st.episodes)
         if cnt:
             step_idx = np.empty(cnt, dtype=np.int32)
             ret = np.empty(cnt, dtype=np.float32)
             lib.qe_episode_log(algo.handle, cnt, _lib.ptr(step_idx, C.c_int32), None, _lib.ptr(ret, C.c_float))
             history.append(ret)
-            ep_steps.append(step_idx + done)
+            if done:
+                step_idx += done
+            ep_steps.append(step_idx)
         for f in total:
             total[f] += getattr(st, f)
 
@@ -93,76 +117,105 @@ class GpuRolloutQLearning(BaseRuntime):
         lib = _lib.load()
         algo = self.algorithm
         n = env.num_agents
+        env._resident = None  # the device state moves on
         mode = _lib.LEARN_ITER if self.learn_mode == "iter" else _lib.LEARN_VEC
         total = {"kernel_ms": 0.0, "launches": 0, "episodes": 0, "involved": 0, "episodes_dropped": 0,
-                 "dominant_ms": 0.0, "dominant_launches": 0, "dominant_env_steps": 0}
+                 "dominant_ms": 0.0, "dominant_launches": 0, "dominant_env_steps": 0, "device_clock_ms": 0.0}
         history, ep_steps, traces = [], [], []
-        chunk_max = max(1, _EP_LOG_CAPACITY // n)
+        chunk_max = max(1, int(lib.qe_rollout_chunk_limit(algo.handle, env.handle, 1 if learn else 0)))
         sync = self.delta_sync if learn else None
         if sync is not None:
             chunk_max = min(chunk_max, self.sync_every)
-        if learn and not self.trace_actions:
+        collect_trace = self.trace_actions is not None and self.trace_actions is not False
+        if learn and not collect_trace:
             # Pipelined: chunk k+1 is enqueued before the results of chunk k are read back, so the GPU
             # never waits for the host (schedule arithmetic, episode-log handling, replica exchange).
             chunk_max = min(chunk_max, self._PIPELINE_CHUNK)
-            sizes = [min(chunk_max, steps - d) for d in range(0, steps, chunk_max)]
-            starts = np.cumsum([0] + sizes[:-1])
-
-            # the schedule values of the whole call go to the device once (qe_schedule_plan); the chunks
-            # consume them in order
             eps = _schedule_values(self.exploration_rate_schedule, n, steps)
             lr = _schedule_values(self.lr_schedule, n, steps)
-            _lib.check(lib.qe_schedule_plan(algo.handle, _lib.ptr(eps, C.c_double), _lib.ptr(lr, C.c_double), steps))
-
-            def begin(k):
-                _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, sizes[k], None, None, mode, k & 1))
-
-            def end(k):
+            if steps <= chunk_max:
+                # one launch: the schedule values travel with it (inside the kernel arguments when short)
                 st = _lib.RolloutStats()
-                _lib.check(lib.qe_rollout_end(algo.handle, k & 1, C.byref(st)))
-                self._collect(lib, algo, st, int(starts[k]), total, history, ep_steps)
+                _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, steps, _f64_ptr(eps), _f64_ptr(lr), mode, 0))
+                try:
+                    if sync is not None:
+                        sync.exchange(steps * n)
+                        _lib.check(lib.qe_delta_log_reset(algo.handle))
+                finally:
+                    rc = lib.qe_rollout_end(algo.handle, 0, C.byref(st))
+                _lib.check(rc)
+                self._collect(lib, algo, st, 0, total, history, ep_steps)
+                if sync is not None:
+                    sync.flush()
+            else:
+                sizes = [min(chunk_max, steps - d) for d in range(0, steps, chunk_max)]
+                starts = np.cumsum([0] + sizes[:-1])
+                # the schedule values of the whole call go to the device once (qe_schedule_plan); the
+                # chunks consume them in order
+                _lib.check(lib.qe_schedule_plan(algo.handle, _f64_ptr(eps), _f64_ptr(lr), steps))
+                begun = []  # chunks enqueued and not yet collected
 
-            def exchange(k):
-                if sync is not None:  # all-gather of chunk k's (cell, delta) records, stream-ordered
-                    sync.exchange(sizes[k] * n)
-                    _lib.check(lib.qe_delta_log_reset(algo.handle))
+                def begin(k):
+                    _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, sizes[k], None, None, mode, k & 1))
+                    begun.append(k)
 
-            begin(0)
-            for k in range(1, len(sizes)):
-                exchange(k - 1)
-                begin(k)
-                end(k - 1)
-            exchange(len(sizes) - 1)
-            end(len(sizes) - 1)
-            if sync is not None:
-                sync.flush()  # remote deltas still in flight are applied before returning
+                def end(k):
+                    st = _lib.RolloutStats()
+                    begun.remove(k)
+                    _lib.check(lib.qe_rollout_end(algo.handle, k & 1, C.byref(st)))
+                    self._collect(lib, algo, st, int(starts[k]), total, history, ep_steps)
+
+                def exchange(k):
+                    if sync is not None:  # all-gather of chunk k's (cell, delta) records, stream-ordered
+                        sync.exchange(sizes[k] * n)
+                        _lib.check(lib.qe_delta_log_reset(algo.handle))
+
+                try:
+                    begin(0)
+                    for k in range(1, len(sizes)):
+                        exchange(k - 1)
+                        begin(k)
+                        end(k - 1)
+                    exchange(len(sizes) - 1)
+                    end(len(sizes) - 1)
+                finally:
+                    # an exception (e.g. the reference's IndexError for an agent without a selectable
+                    # action, or a failed collective) must not leave a slot marked busy: drain what was
+                    # begun, ignoring its status, and complete the exchange in flight
+                    for k in list(begun):
+                        lib.qe_rollout_end(algo.handle, k & 1, None)
+                    begun.clear()
+                    if sync is not None:
+                        sync.flush()  # remote deltas still in flight are applied before returning
         else:
             done = 0
-            while done < steps:
-                k = min(chunk_max, steps - done)
-                st = _lib.RolloutStats()
-                if learn:
-                    eps = _schedule_values(self.exploration_rate_schedule, n, k)
-                    lr = _schedule_values(self.lr_schedule, n, k)
-                    trace = np.empty((k, n), dtype=np.int32)
-                    _lib.check(lib.qe_rollout(algo.handle, env.handle, k, _lib.ptr(eps, C.c_double),
-                                              _lib.ptr(lr, C.c_double), mode, _lib.ptr(trace, C.c_int32),
-                                              C.byref(st)))
-                    traces.append(trace)
-                    if sync is not None:
-                        sync.exchange(k * n)
-                        _lib.check(lib.qe_delta_log_reset(algo.handle))
-                else:
-                    _lib.check(lib.qe_evaluate(algo.handle, env.handle, k, C.byref(st)))
-                self._collect(lib, algo, st, done, total, history, ep_steps)
-                done += k
-            if sync is not None:
-                sync.flush()
+            try:
+                while done < steps:
+                    k = min(chunk_max, steps - done)
+                    st = _lib.RolloutStats()
+                    if learn:
+                        eps = _schedule_values(self.exploration_rate_schedule, n, k)
+                        lr = _schedule_values(self.lr_schedule, n, k)
+                        trace = np.empty((k, n), dtype=np.int32)
+                        _lib.check(lib.qe_rollout(algo.handle, env.handle, k, _f64_ptr(eps), _f64_ptr(lr), mode,
+                                                  _lib.ptr(trace, C.c_int32), C.byref(st)))
+                        traces.append(trace)
+                        if sync is not None:
+                            sync.exchange(k * n)
+                            _lib.check(lib.qe_delta_log_reset(algo.handle))
+                    else:
+                        _lib.check(lib.qe_evaluate(algo.handle, env.handle, k, C.byref(st)))
+                    self._collect(lib, algo, st, done, total, history, ep_steps)
+                    done += k
+            finally:
+                if sync is not None:
+                    sync.flush()
         self.last_stats = total
         if traces:
-            self.trace_actions = np.concatenate(traces)
-        rets = np.concatenate(history) if history else np.empty(0, dtype=np.float32)
-        at = np.concatenate(ep_steps) if ep_steps else np.empty(0, dtype=np.int32)
+            self.last_trace = np.concatenate(traces)
+            self.trace_actions = self.last_trace
+        rets = (history[0] if len(history) == 1 else np.concatenate(history)) if history else np.empty(0, dtype=np.float32)
+        at = (ep_steps[0] if len(ep_steps) == 1 else np.concatenate(ep_steps)) if ep_steps else np.empty(0, dtype=np.int32)
         return rets, at
 
     def run_steps(self, steps, env, curr_state_dict=None):
@@ -170,21 +223,37 @@ class GpuRolloutQLearning(BaseRuntime):
             return self._run_steps_host(steps, env, curr_state_dict)
         env.bind(self.algorithm)
         if curr_state_dict is None:
-            env.reset()
-        else:
-            env.restore(curr_state_dict["states"], curr_state_dict["rewards"])
+            env.reset_device()
+        elif not env.is_resident(curr_state_dict):
+            # a state dict from elsewhere (another process, an edited copy): hand it to the device.  The
+            # dict this runtime returned last is recognised and costs nothing -- the environments never
+            # left the GPU.
+            env.restore(curr_state_dict["states"], curr_state_dict["rewards"], curr_state_dict.get("aux"))
         rets, _ = self._rollout(env, steps, learn=True)
         reward_history = self._history(rets)
-        states, agent_rewards = env.observe()
+        state_dict = env.state_dict()
+        state_dict["episode_rewards"] = reward_history
+        # not part of the reference's dict (single_thread_runtime.py:70-75): what an exact resume in a
+        # fresh process needs besides the table -- draw counter and schedule values (restore_training_state)
+        state_dict["rng_step"] = self.algorithm.step_counter
+        state_dict["lr"] = self.lr_schedule.get_value()
+        state_dict["exploration_rate"] = self.exploration_rate_schedule.get_value()
         return (
             # sum(reward_history) / len(reward_history) of the reference (:67): a sequential float32
             # accumulation, which is what cumsum computes; ZeroDivisionError if no episode ended
             _sequential_sum(rets) / len(reward_history),
             reward_history,
             env,
-            {"states": states, "infos": [{}] * env.num_agents, "rewards": agent_rewards,
-             "episode_rewards": reward_history},
+            state_dict,
         )
+
+    def restore_training_state(self, state_dict) -> None:
+        """Continue a run in a fresh process exactly where ``state_dict`` (returned by ``run_steps``,
+        e.g. un-pickled) left it: draw counter and both schedule values.  The table is restored with
+        ``algorithm.load(filename)``, the environments by passing the dict to ``run_steps``."""
+        self.algorithm.step_counter = int(state_dict["rng_step"])
+        self.lr_schedule.set_value(state_dict["lr"])
+        self.exploration_rate_schedule.set_value(state_dict["exploration_rate"])
 
     def _run_steps_host(self, steps, env, curr_state_dict):
         reward_history = []
@@ -193,7 +262,7 @@ class GpuRolloutQLearning(BaseRuntime):
             agent_rewards = np.zeros(_count_agents(states), dtype=np.float32)
         else:
             states, infos = curr_state_dict["states"], curr_state_dict["infos"]
-            agent_rewards = curr_state_dict["rewards"]
+            agent_rewards = np.array(curr_state_dict["rewards"], dtype=np.float32)  # accumulated in place below
         for _ in range(steps):
             states, infos = self.run_single_step(env, states, agent_rewards, reward_history)
         return (
@@ -208,7 +277,7 @@ class GpuRolloutQLearning(BaseRuntime):
         if not isinstance(env, DeviceVecEnv):
             return super().evaluate_steps(env, steps)
         env.bind(self.algorithm)
-        env.reset(seed=42)
+        env.reset_device(seed=42)
         vector_steps = len(range(0, steps, env.num_agents))
         rets, _ = self._rollout(env, vector_steps, learn=False)
         history = list(rets)
@@ -218,7 +287,7 @@ class GpuRolloutQLearning(BaseRuntime):
         if not isinstance(env, DeviceVecEnv):
             return super().evaluate_episodes(env, episodes)
         env.bind(self.algorithm)
-        env.reset(seed=42)
+        env.reset_device(seed=42)
         start = self.algorithm.step_counter
         history, used, chunk = [], 0, 64
         while len(history) < episodes:

@@ -2,6 +2,8 @@
 // state, launches the gfx950 kernels of qe_kernels.h, exports the C ABI of include/qlearn_engine.h.
 #include "../../include/qlearn_engine.h"
 
+#include <time.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -124,6 +126,7 @@ constexpr int64_t LISTED_MIN_AGENTS = 16384;  // from here on the rounds walk co
 constexpr int LISTED_MIN_ROUNDS = 6;   // ... and only when at least this many rounds run
 constexpr int LISTED_RECOMPACT = 3;    // rounds on the first list before the second compaction
 constexpr unsigned LISTED_GRID = 1024; // blocks of a listed round (grid-stride)
+constexpr long long HOST_LOG_CAP = 1 << 18;  // episode-log entries of a slot's host result block (persistent path)
 
 // Everything one in-flight rollout owns, so that the next rollout can be enqueued before the results
 // of the previous one are read back.
@@ -146,9 +149,28 @@ struct RolloutSlot {
     int rounds = 4;  // token rounds per step of this call (wide mode)
     int64_t plan_offset = -1;  // >= 0: schedules come from the engine's plan at this offset
     double* dbg = nullptr;  // env->vinc of the rollout in flight (diagnostic builds)
+    // Host result block (persistent path): page-locked, host-coherent memory the rollout kernel writes
+    // itself -- control words, final observations / env state / running returns, episode log -- so that
+    // qe_rollout_end neither synchronises a stream nor issues a copy: it spins on hb->seq.
+    HostBlock* hb = nullptr;
+    int32_t* hb_obs = nullptr;
+    uint32_t* hb_aux = nullptr;
+    float* hb_acc = nullptr;
+    unsigned long long* hb_key = nullptr;
+    float* hb_ret = nullptr;
+    size_t hb_agents = 0;
+    unsigned long long seq = 0;  // value hb->seq takes when the rollout in flight has published
+    bool fast = false;           // the rollout in flight publishes through the host block
+    bool inline_sched = false;   // ... and carries its schedule values in its kernel arguments
+    InlineSched sched{};
+    struct qe_env* env = nullptr;  // environment of the rollout in flight
     void release() {
         if (ctrl) (void)hipFree(ctrl);
         ctrl = nullptr;
+        for (void* h : {(void*)hb, (void*)hb_obs, (void*)hb_aux, (void*)hb_acc, (void*)hb_key, (void*)hb_ret})
+            if (h) (void)hipHostFree(h);
+        hb = nullptr; hb_obs = nullptr; hb_aux = nullptr; hb_acc = nullptr; hb_key = nullptr; hb_ret = nullptr;
+        hb_agents = 0;
         thr.release(); ep_key.release(); lr.release(); ep_ret.release();
         ep_key_packed.release(); ep_ret_packed.release();
         h_thr.release(); h_key.release(); h_lr.release(); h_ret.release(); h_ctrl.release();
@@ -170,12 +192,16 @@ struct qe_engine {
     int32_t A = 0, ld = 0, L = 1, lshift = 0;
     double gamma = 0.97;
     uint64_t seed = 0, step_ctr = 0;
+    double wall_clock_khz = 100000.0;  // rate of wall_clock64() (s_memrealtime), ticks per millisecond
     uint32_t agent_offset = 0;
     int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
     int opt_graph = 1; // QE_OPT_USE_GRAPH
     int opt_rounds = 0; // QE_OPT_TOKEN_ROUNDS (0 = automatic)
     int auto_rounds = 4; // wide mode: rounds chosen from the previous call's statistics
     int64_t listed_min = LISTED_MIN_AGENTS;  // QE_OPT_LISTED_MIN_AGENTS
+    int opt_timing = 1;  // QE_OPT_EVENT_TIMING: bracket rollouts with HIP events (persistent path: off = in-kernel clock only)
+    int opt_host_block = 1;  // QE_OPT_HOST_BLOCK: persistent rollouts publish through the host result block
+    unsigned long long seq_ctr = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
     void* q = nullptr;
@@ -226,6 +252,11 @@ struct qe_env {
     DevBuf<uint8_t> term, pred, masks;
     DevBuf<uint32_t> aux, bitmap, adv_bitmap;
     DevBuf<double> vinc;
+    // host copy of (observations, env-internal state, running returns) left by the latest rollout's
+    // result block; valid until anything else changes the device state
+    const int32_t* mirror_obs = nullptr;
+    const uint32_t* mirror_aux = nullptr;
+    const float* mirror_acc = nullptr;
 };
 
 namespace {
@@ -250,7 +281,7 @@ Ctx<T> base_ctx(qe_engine* e, int64_t N) {
     Ctx<T> c{};
     c.q = (T*)e->q; c.S = e->S; c.A = e->A; c.ld = e->ld; c.L = e->L; c.lshift = e->lshift;
     c.N = N; c.stamps = e->stamps; c.ctrl = e->ctrl;
-    c.thr = e->thr.p; c.lr = e->lr.p;
+    c.thr = (const QE_AS4 unsigned long long*)e->thr.p; c.lr = (const QE_AS4 double*)e->lr.p;
     c.seed_lo = (uint32_t)e->seed; c.seed_hi = (uint32_t)(e->seed >> 32);
     c.agent_offset = e->agent_offset; c.step0 = e->step_ctr; c.gamma = e->gamma;
     c.ep_key = e->ep_key.p; c.ep_ret = e->ep_ret.p; c.ep_cap = e->ep_cap;
@@ -305,15 +336,51 @@ static int slot_create(qe_engine* e, RolloutSlot& sl) {
     return QE_OK;
 }
 
-int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps, const double* lr, bool use_plan) {
+// Page-locked result block of a slot (persistent path), sized for `agents` agents.
+static int slot_host_block(qe_engine* e, RolloutSlot& sl, size_t agents) {
+    (void)e;
+    const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+    if (!sl.hb) {
+        HIP_TRY(hipHostMalloc((void**)&sl.hb, sizeof(HostBlock), flags));
+        memset(sl.hb, 0, sizeof(HostBlock));
+        HIP_TRY(hipHostMalloc((void**)&sl.hb_key, (size_t)HOST_LOG_CAP * sizeof(unsigned long long), flags));
+        HIP_TRY(hipHostMalloc((void**)&sl.hb_ret, (size_t)HOST_LOG_CAP * sizeof(float), flags));
+    }
+    if (agents > sl.hb_agents) {
+        for (void* h : {(void*)sl.hb_obs, (void*)sl.hb_aux, (void*)sl.hb_acc})
+            if (h) (void)hipHostFree(h);
+        sl.hb_obs = nullptr; sl.hb_aux = nullptr; sl.hb_acc = nullptr; sl.hb_agents = 0;
+        const size_t want = std::max(agents, (size_t)1024);
+        HIP_TRY(hipHostMalloc((void**)&sl.hb_obs, want * 4, flags));
+        HIP_TRY(hipHostMalloc((void**)&sl.hb_aux, want * 4, flags));
+        HIP_TRY(hipHostMalloc((void**)&sl.hb_acc, want * 4, flags));
+        sl.hb_agents = want;
+    }
+    return QE_OK;
+}
+
+static bool persistent_path(const qe_engine* e, const qe_env* env, int learn) {
+    return learn && env->N * e->L <= PERSIST_MAX_LANES && env->N <= PERSIST_MAX_AGENTS &&
+           (e->opt_path == 0 || e->opt_path == 2);
+}
+
+int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps, const double* lr, bool use_plan,
+                 bool persistent) {
     // both result slots are set up at the first rollout: a later, longer call that pipelines through the
     // second slot does not pay for allocations then
     for (RolloutSlot& each : e->slots)
         if (int rc = slot_create(e, each)) return rc;
     sl.plan_offset = -1;
+    sl.inline_sched = false;
     if (use_plan) {  // the values are already on the device
         sl.plan_offset = e->plan_cursor;
         e->plan_cursor += steps;
+        return QE_OK;
+    }
+    if (persistent && eps && lr && steps <= INLINE_SCHED_STEPS) {
+        // short rollout on the persistent path: the values ride in the kernel arguments
+        for (int64_t t = 0; t < steps; ++t) { sl.sched.thr[t] = eps_threshold(eps[t]); sl.sched.lr[t] = lr[t]; }
+        sl.inline_sched = true;
         return QE_OK;
     }
     HIP_TRY(sl.h_thr.ensure((size_t)steps));
@@ -440,8 +507,13 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                        int32_t* trace_host) {
     Ctx<T> c = env_ctx<T>(e, env);
     c.mode = mode;
-    c.ctrl = sl.ctrl; c.thr = sl.thr.p; c.lr = sl.lr.p;
-    if (sl.plan_offset >= 0) { c.thr = e->plan_thr.p + sl.plan_offset; c.lr = e->plan_lr.p + sl.plan_offset; }
+    c.ctrl = sl.ctrl;
+    c.thr = (const QE_AS4 unsigned long long*)sl.thr.p; c.lr = (const QE_AS4 double*)sl.lr.p;
+    if (sl.plan_offset >= 0) {
+        c.thr = (const QE_AS4 unsigned long long*)(e->plan_thr.p + sl.plan_offset);
+        c.lr = (const QE_AS4 double*)(e->plan_lr.p + sl.plan_offset);
+    }
+    if (sl.inline_sched) { c.thr = nullptr; c.lr = nullptr; }  // in the kernel-argument segment
     c.ep_key = sl.ep_key.p; c.ep_ret = sl.ep_ret.p; c.ep_cap = e->ep_cap;
     const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
     if (trace_host) {
@@ -452,8 +524,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         c.dlog = e->dlog; c.dlog_base = e->dlog_count; c.dlog_cap = e->dlog_cap;
     }
     const int64_t lanes = env->N * e->L;
-    const bool persistent = learn && lanes <= PERSIST_MAX_LANES && env->N <= PERSIST_MAX_AGENTS &&
-                            (e->opt_path == 0 || e->opt_path == 2);
+    const bool persistent = persistent_path(e, env, learn);
     if (learn && e->opt_path == 2 && !persistent)
         return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and num_agents * lanes_per_row <= 1024 (have %lld lanes)",
                     (long long)lanes);
@@ -475,12 +546,24 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     sl.wide = wide;
     sl.trace_host = trace_host;
     sl.dbg = env->vinc.p;
+    sl.env = env;
+    env->mirror_obs = nullptr; env->mirror_aux = nullptr; env->mirror_acc = nullptr;  // the device state moves on
+    // The persistent kernel publishes its results itself (host result block).  With an action trace the
+    // trace still has to be copied out of device memory, which needs the end-of-kernel event anyway.
+    sl.fast = persistent && e->opt_host_block && !trace_host;
+    if (sl.fast) {
+        if (int rc = slot_host_block(e, sl, (size_t)env->N)) return rc;
+        sl.seq = ++e->seq_ctr;
+        c.hb = sl.hb; c.hb_obs = sl.hb_obs; c.hb_aux = sl.hb_aux; c.hb_acc = sl.hb_acc; c.hb_seq = sl.seq;
+        c.ep_key = sl.hb_key; c.ep_ret = sl.hb_ret; c.ep_cap = HOST_LOG_CAP;
+    }
     if (!persistent) HIP_TRY(hipMemsetAsync(sl.ctrl, 0, sizeof(Ctrl), e->stream));  // persistent kernel: in-kernel
     // Start marker of the timed region.  With the delta log attached a training call is chopped into
     // short launches (one per replica exchange) and every marker in the stream costs ~6 us between two
     // of them, so only every eighth launch is timed there; the others are reported at the last
     // measured time per step (and do not count as roofline samples).
     sl.timed = !(persistent && c.dlog) || (e->timing_skip++ % 8) == 0;
+    if (sl.fast && !e->opt_timing) sl.timed = false;  // in-kernel clock only
     if (sl.timed) HIP_TRY(hipEventRecord(sl.ev0, e->stream));
     if (persistent) {
         const unsigned block = (unsigned)((lanes + 63) / 64 * 64);
@@ -492,16 +575,16 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             const bool lean = mode == QE_LEARN_ITER && !c.trace;
             if ((LCV == 2 || LCV == 4) && block <= 512 && lean && !c.dlog)
                 hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL, SMALL == 512 ? 1 : 0>), dim3(1),
-                                   dim3(block), 0, e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+                                   dim3(block), 0, e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if ((LCV == 2 || LCV == 4) && block <= 512 && lean)
                 hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL, SMALL == 512 ? 2 : 0>), dim3(1),
-                                   dim3(block), 0, e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+                                   dim3(block), 0, e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if ((LCV == 2 || LCV == 4) && block <= 512)
                 hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL>), dim3(1),
-                                   dim3(block), 0, e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+                                   dim3(block), 0, e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else
                 hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, 1024>), dim3(1), dim3(block), 0,
-                                   e->stream, c, ev, (long long)steps, FLAG_ACCOUNT);
+                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
         };
         if constexpr (std::is_same<Env, HashEnv>::value) {
             switch (e->L) {  // compile-time lane-group width: reductions become DPP moves
@@ -570,11 +653,33 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                            sl.ep_key_packed.p, sl.ep_ret_packed.p);
         ++sl.launches;
     }
-    HIP_TRY(hipEventRecord(sl.ev1, e->stream));
+    if (!sl.fast || sl.timed) HIP_TRY(hipEventRecord(sl.ev1, e->stream));
     HIP_TRY(hipGetLastError());
     if (c.dlog) e->dlog_count = std::min<long long>(e->dlog_count + steps * env->N, e->dlog_cap);
     e->step_ctr += (uint64_t)steps;
     sl.busy = true;
+    return QE_OK;
+}
+
+// Host side of the result block: spin until the rollout in this slot has published (a short rollout
+// completes within tens of microseconds -- less than a blocking stream synchronisation takes to wake
+// up), back off to short sleeps for long ones, and notice a stream that drained without publishing.
+static int wait_host_block(qe_engine* e, RolloutSlot& sl) {
+    auto published = [&] { return __atomic_load_n(&sl.hb->seq, __ATOMIC_ACQUIRE) == sl.seq; };
+    for (long spin = 0; !published(); ++spin) {
+        if (spin < 200000) { __builtin_ia32_pause(); continue; }
+        if ((spin & 63) == 0) {
+            const hipError_t q = hipStreamQuery(e->stream);
+            if (q == hipSuccess) {
+                if (published()) break;
+                return fail(QE_ERR_NO_DEVICE, "the rollout kernel finished without publishing its result block");
+            }
+            if (q != hipErrorNotReady)
+                return fail(QE_ERR_NO_DEVICE, "HIP error %d (%s) while waiting for a rollout", (int)q, hipGetErrorString(q));
+        }
+        struct timespec ts = {0, 20000};
+        nanosleep(&ts, nullptr);
+    }
     return QE_OK;
 }
 
@@ -583,18 +688,36 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
 int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
     if (!sl.busy) return fail(QE_ERR_INVALID, "no rollout in flight in this slot");
     sl.busy = false;
-    HIP_TRY(hipStreamWaitEvent(e->copy_stream, sl.ev1, 0));
-    HIP_TRY(hipMemcpyAsync(sl.h_ctrl.p, sl.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->copy_stream));
-    HIP_TRY(hipStreamSynchronize(e->copy_stream));
-    HIP_TRY(hipGetLastError());
+    Ctrl fin{};
     float ms = 0;
+    double clock_ms = 0.0;
+    if (sl.fast) {
+        if (int rc = wait_host_block(e, sl)) return rc;
+        fin.ep_count = sl.hb->ep_count; fin.involved_total = sl.hb->involved_total; fin.error = sl.hb->error;
+        clock_ms = (double)(sl.hb->clk1 - sl.hb->clk0) / e->wall_clock_khz;
+        if (sl.timed) HIP_TRY(hipEventSynchronize(sl.ev1));
+        // the environment's state after this rollout sits in the block (unless the next rollout of a
+        // pipelined call is already moving it on)
+        const RolloutSlot& other = e->slots[&sl == &e->slots[0] ? 1 : 0];
+        if (sl.env && !(other.busy && other.env == sl.env)) {
+            sl.env->mirror_obs = sl.hb_obs; sl.env->mirror_aux = sl.hb_aux; sl.env->mirror_acc = sl.hb_acc;
+        }
+    } else {
+        HIP_TRY(hipStreamWaitEvent(e->copy_stream, sl.ev1, 0));
+        HIP_TRY(hipMemcpyAsync(sl.h_ctrl.p, sl.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+        HIP_TRY(hipGetLastError());
+        fin = *sl.h_ctrl.p;
+    }
     if (sl.timed) {
         HIP_TRY(hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
         if (sl.steps > 0) e->ms_per_step_est = (double)ms / (double)sl.steps;
+    } else if (sl.fast) {
+        ms = (float)clock_ms;
+        if (sl.steps > 0) e->ms_per_step_est = clock_ms / (double)sl.steps;
     } else {
         ms = (float)(e->ms_per_step_est * (double)sl.steps);
     }
-    const Ctrl fin = *sl.h_ctrl.p;
     if (sl.wide && sl.steps > 0) {
         // Number of chip-wide token rounds of the NEXT calls: every round roughly halves the agents that
         // are left for the single-workgroup ordered path; aim at a few hundred of those per step.
@@ -610,7 +733,7 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
     long long seg_got[64];
     if (sl.persistent) {
         total = (long long)fin.ep_count;
-        got = std::min<long long>(total, e->ep_cap);
+        got = std::min<long long>(total, sl.fast ? HOST_LOG_CAP : e->ep_cap);
     } else {
         for (int k = 0; k < 64; ++k) {
             total += fin.ep_seg[k];
@@ -619,7 +742,9 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         }
     }
     e->ep_host.resize((size_t)got);
-    if (got) {
+    if (got && sl.fast) {  // the kernel wrote the log into page-locked memory itself
+        for (long long k = 0; k < got; ++k) e->ep_host[(size_t)k] = {sl.hb_key[k], sl.hb_ret[k]};
+    } else if (got) {
         // page-locked staging grows in big strides (re-allocating it costs milliseconds, and a timed call
         // usually finishes several times the episodes of its warm-up)
         if ((size_t)got > sl.h_key.cap || (size_t)got > sl.h_ret.cap) {
@@ -664,6 +789,7 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         if (sl.persistent && sl.timed) {  // the one launch IS the timed region
             st->dominant_ms = ms; st->dominant_launches = 1; st->dominant_env_steps = sl.steps * sl.N;
         }
+        st->device_clock_ms = clock_ms;
     }
 #ifdef QE_STAMPS
     if (getenv("QE_PRINT_STAMPS")) {
@@ -737,6 +863,11 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     if (device < 0 || device >= ndev) return fail(QE_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
     HIP_TRY(hipSetDevice(device));
     qe_engine* e = new qe_engine();
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
+            e->wall_clock_khz = (double)khz;
+    }
     e->device = device; e->dtype = dtype; e->S = S; e->A = A; e->ld = (A + 3) / 4 * 4;
     e->L = lanes_per_row(e->ld);
     if (e->L > 64) e->L = 64;  // A > 256: the wave-per-row kernels take over
@@ -745,12 +876,9 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     // tuning overrides for experiments (same meaning as the qe_set_option knobs; results never change)
     if (const char* v = getenv("QE_TOKEN_ROUNDS")) e->opt_rounds = std::max(0, std::min(MAX_TOKEN_ROUNDS, atoi(v)));
     if (const char* v = getenv("QE_LISTED_MIN_AGENTS")) e->listed_min = std::max(1, atoi(v));
-    // rocprofv3 (ROCm 7.2) segfaults when a captured graph is replayed under --kernel-trace: launch
-    // eagerly when its tool library is preloaded (kernel durations are the same either way)
-    for (const char* var : {"ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "HSA_TOOLS_LIB"})
-        if (const char* v = getenv(var))
-            if (strstr(v, "rocprofiler") || strstr(v, "rocprof")) e->opt_graph = 0;
-    if (const char* v = getenv("QE_USE_GRAPH")) e->opt_graph = atoi(v) != 0;
+    if (const char* v = getenv("QE_USE_GRAPH")) e->opt_graph = atoi(v) != 0;  // see profiles/README.md
+    if (const char* v = getenv("QE_HOST_BLOCK")) e->opt_host_block = atoi(v) != 0;
+    if (const char* v = getenv("QE_EVENT_TIMING")) e->opt_timing = atoi(v) != 0;
     const size_t bytes = (size_t)S * e->ld * e->esize();
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
@@ -823,6 +951,8 @@ int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_USE_GRAPH && (value == 0 || value == 1)) { e->opt_graph = (int)value; return QE_OK; }
     if (option == QE_OPT_LISTED_MIN_AGENTS && value >= 1) { e->listed_min = value; return QE_OK; }
     if (option == QE_OPT_TOKEN_ROUNDS && value >= 0 && value <= MAX_TOKEN_ROUNDS) { e->opt_rounds = (int)value; return QE_OK; }
+    if (option == QE_OPT_EVENT_TIMING && (value == 0 || value == 1)) { e->opt_timing = (int)value; return QE_OK; }
+    if (option == QE_OPT_HOST_BLOCK && (value == 0 || value == 1)) { e->opt_host_block = (int)value; return QE_OK; }
     return fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 
@@ -1109,9 +1239,12 @@ int qe_env_destroy(qe_env* env) {
     return QE_OK;
 }
 
+static void env_touched(qe_env* env) { env->mirror_obs = nullptr; env->mirror_aux = nullptr; env->mirror_acc = nullptr; }
+
 int qe_env_reset(qe_env* env, int32_t has_seed, uint32_t seed) {
     qe_engine* e = env->e;
     HIP_TRY(hipSetDevice(e->device));
+    env_touched(env);
     if (has_seed) env->p.seed = seed;
     const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
     int rc = by_kind(env->p.kind, [&](auto tag) {
@@ -1128,6 +1261,11 @@ int qe_env_reset(qe_env* env, int32_t has_seed, uint32_t seed) {
 
 int qe_env_observe(qe_env* env, int32_t* obs, uint8_t* masks, float* agent_rewards) {
     qe_engine* e = env->e;
+    if (env->mirror_obs && !masks) {  // left in page-locked memory by the latest rollout: no device round trip
+        if (obs) memcpy(obs, env->mirror_obs, (size_t)env->N * 4);
+        if (agent_rewards) memcpy(agent_rewards, env->mirror_acc, (size_t)env->N * 4);
+        return QE_OK;
+    }
     HIP_TRY(hipSetDevice(e->device));
     if (obs) HIP_TRY(hipMemcpyAsync(obs, env->n.p, env->N * 4, hipMemcpyDeviceToHost, e->stream));
     if (agent_rewards) HIP_TRY(hipMemcpyAsync(agent_rewards, env->acc.p, env->N * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1153,6 +1291,7 @@ int qe_env_observe(qe_env* env, int32_t* obs, uint8_t* masks, float* agent_rewar
 int qe_env_restore(qe_env* env, const int32_t* obs, const uint32_t* aux, const float* agent_rewards) {
     qe_engine* e = env->e;
     HIP_TRY(hipSetDevice(e->device));
+    env_touched(env);
     if (obs) {
         if (int rc = check_indices(obs, env->N, e->S, "obs")) return rc;
         HIP_TRY(hipMemcpyAsync(env->n.p, obs, env->N * 4, hipMemcpyHostToDevice, e->stream));
@@ -1164,8 +1303,12 @@ int qe_env_restore(qe_env* env, const int32_t* obs, const uint32_t* aux, const f
 }
 
 int qe_env_aux(qe_env* env, uint32_t* aux) {
+    if (!aux) return fail(QE_ERR_INVALID, "aux is NULL");
+    if (env->mirror_aux) { memcpy(aux, env->mirror_aux, (size_t)env->N * 4); return QE_OK; }
     HIP_TRY(hipSetDevice(env->e->device));
-    HIP_TRY(hipMemcpy(aux, env->aux.p, env->N * 4, hipMemcpyDeviceToHost));
+    // on the engine's stream (a non-blocking stream: the null stream would not be ordered behind it)
+    HIP_TRY(hipMemcpyAsync(aux, env->aux.p, env->N * 4, hipMemcpyDeviceToHost, env->e->stream));
+    HIP_TRY(hipStreamSynchronize(env->e->stream));
     return QE_OK;
 }
 
@@ -1175,6 +1318,7 @@ int qe_env_step(qe_env* env, const int32_t* actions, int32_t* obs, float* reward
     if (!actions) return fail(QE_ERR_INVALID, "actions is NULL");
     if (int rc = check_indices(actions, env->N, e->A, "actions")) return rc;
     HIP_TRY(hipSetDevice(e->device));
+    env_touched(env);
     HIP_TRY(hipMemcpyAsync(env->a.p, actions, env->N * 4, hipMemcpyHostToDevice, e->stream));
     const EnvCtx ev = make_envctx(e, &env->p, nullptr, 0);
     int rc = by_kind(env->p.kind, [&](auto tag) {
@@ -1205,7 +1349,8 @@ static int begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, co
     RolloutSlot& sl = e->slots[slot];
     if (sl.busy) return fail(QE_ERR_INVALID, "slot %d still has a rollout in flight (call qe_rollout_end)", slot);
     HIP_TRY(hipSetDevice(e->device));
-    if (int rc = slot_prepare(e, sl, steps, learn ? eps : nullptr, learn ? lr : nullptr, use_plan)) return rc;
+    if (int rc = slot_prepare(e, sl, steps, learn ? eps : nullptr, learn ? lr : nullptr, use_plan,
+                              persistent_path(e, env, learn) && !trace)) return rc;
     return e->dtype == QE_F32 ? rollout_begin_dispatch<float>(e, env, sl, steps, mode, learn, trace)
                               : rollout_begin_dispatch<double>(e, env, sl, steps, mode, learn, trace);
 }
@@ -1248,6 +1393,16 @@ int qe_schedule_plan(qe_engine* e, const double* eps, const double* lr, int64_t 
     HIP_TRY(hipStreamWaitEvent(e->stream, e->plan_ready, 0));
     e->plan_count = count;
     return QE_OK;
+}
+
+int64_t qe_rollout_chunk_limit(qe_engine* e, qe_env* env, int32_t learn) {
+    if (!e || !env) return 0;
+    // worst case: every agent finishes an episode in every step
+    if (persistent_path(e, env, learn) && e->opt_host_block) return std::max<int64_t>(1, HOST_LOG_CAP / env->N);
+    if (persistent_path(e, env, learn)) return std::max<int64_t>(1, e->ep_cap / env->N);
+    // step-wise / evaluation kernels: 64 log segments chosen by (agent + step) & 63, each ep_cap / 64 entries
+    const int64_t per_seg_step = (env->N + 63) / 64;
+    return std::max<int64_t>(1, (e->ep_cap >> 6) / per_seg_step);
 }
 
 int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats) {

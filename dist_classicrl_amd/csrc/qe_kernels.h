@@ -65,6 +65,27 @@ struct DeltaEntry {
     float delta;
 };
 
+// Result block of one rollout in page-locked, host-coherent memory.  The LAST kernel of a rollout
+// writes it (plus the final observations / running returns / episode log next to it) and stores
+// `seq` last with a system-scope release: the host spins on `seq` instead of synchronising the stream
+// and copying the control block, the log and the agent state back one by one.
+struct HostBlock {
+    unsigned long long seq;             // launch sequence number; written last
+    unsigned long long ep_count;        // episode-log entries written
+    unsigned long long involved_total;  // agents that reached the ordered path
+    unsigned long long clk0, clk1;      // s_memrealtime (100 MHz) at the start / end of the launch
+    unsigned int error, pad;
+};
+
+// Schedule values of a short rollout travel in the kernel-argument segment (first parameter of the
+// persistent kernel => offset 0 of the segment): no upload precedes the launch.
+constexpr int INLINE_SCHED_STEPS = 64;
+struct InlineSched {
+    unsigned long long thr[INLINE_SCHED_STEPS];
+    double lr[INLINE_SCHED_STEPS];
+};
+#define QE_AS4 __attribute__((address_space(4)))
+
 template <typename T>
 struct Ctx {
     T* q;
@@ -89,8 +110,10 @@ struct Ctx {
     uint32_t* aux;
     float* acc;
     // per-step schedule values
-    const unsigned long long* thr;  // explore <=> x0 < thr[t]
-    const double* lr;
+    // (constant address space: uniform reads become scalar loads; a short persistent rollout finds
+    // the tables in its own kernel-argument segment, see InlineSched)
+    const QE_AS4 unsigned long long* thr;  // explore <=> x0 < thr[t]
+    const QE_AS4 double* lr;
     // draws
     uint32_t seed_lo, seed_hi, agent_offset;
     unsigned long long step0;
@@ -103,6 +126,12 @@ struct Ctx {
     int32_t* trace;
     DeltaEntry* dlog;
     long long dlog_base, dlog_cap;
+    // host result block (persistent kernel; nullptr: results stay in device memory)
+    HostBlock* hb;
+    int32_t* hb_obs;
+    uint32_t* hb_aux;
+    float* hb_acc;
+    unsigned long long hb_seq;
 };
 
 // Touch counters.  A row is CONTESTED in a step when two agents write it, or one writes it and a
@@ -902,7 +931,7 @@ struct PersistLds {
     unsigned long long ep_key[EP_STAGE];
     float ep_ret[EP_STAGE];
     unsigned char pending[PERSIST_MAX_AGENTS];  // 1 while an agent's deferred update is outstanding
-    alignas(16) unsigned char cold[320];  // the launch context, for the rare paths (see the kernel)
+    alignas(16) unsigned char cold[384];  // the launch context, for the rare paths (see the kernel)
     unsigned def_bits[PERSIST_MAX_AGENTS / 32];  // deferred agents of a step (general ordered path), by index
     unsigned busy[3];     // step t: some row has more than one toucher
     unsigned ep_n;
@@ -933,8 +962,15 @@ __device__ __forceinline__ int ct_insert(PersistLds& l, int tb, int32_t row, uns
 // delta log): the compiler is told so, which removes three families of uniform branches and their
 // operands from the scalar-register budget of the loop.
 template <typename T, class Env, int LC, int BLOCK = 1024, int LEAN = 0>
-__global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx ev, long long steps, int flags) {
+__global__ __launch_bounds__(BLOCK) void k_rollout_persistent(InlineSched /*at offset 0 of the kernarg segment*/,
+                                                              Ctx<T> c, EnvCtx ev, long long steps, int flags) {
     __shared__ PersistLds lds;
+    const unsigned long long clk0 = wall_clock64();
+    if (c.thr == nullptr) {  // short rollout: the schedule values came with the launch
+        const QE_AS4 unsigned char* ka = (const QE_AS4 unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
+        c.thr = (const QE_AS4 unsigned long long*)ka;
+        c.lr = (const QE_AS4 double*)(ka + sizeof(unsigned long long) * INLINE_SCHED_STEPS);
+    }
     if constexpr (LEAN != 0) { c.mode = 0; c.trace = nullptr; }
     if constexpr (LEAN == 1) c.dlog = nullptr;
 #ifdef QE_STAMPS
@@ -1276,11 +1312,31 @@ __global__ __launch_bounds__(BLOCK) void k_rollout_persistent(Ctx<T> c, EnvCtx e
     if (tid == 0 && c.vinc) for (int k = 0; k < 8; ++k) c.vinc[k] = (double)stamp_sum[k];
 #endif
     const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
-    if (lead) { cc.n[i] = p.n; cc.aux[i] = p.aux; cc.acc[i] = acc; }
+    if (lead) {
+        cc.n[i] = p.n; cc.aux[i] = p.aux; cc.acc[i] = acc;
+        if (cc.hb) { cc.hb_obs[i] = p.n; cc.hb_aux[i] = p.aux; cc.hb_acc[i] = acc; }
+    }
     if (tid == 0) {
         cc.ctrl->involved_total = deferred_total;
         cc.ctrl->ep_count = ep_base;
         cc.ctrl->t_local = steps;
+    }
+    if (cc.hb) {
+        // Publish to the host: every wave's stores to the pinned arrays have left the GPU (vmcnt),
+        // then one lane writes the block and, last, the sequence number the host is spinning on.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            HostBlock* hb = cc.hb;
+            hb->ep_count = ep_base;
+            hb->involved_total = deferred_total;
+            hb->error = cc.ctrl->error;
+            hb->clk0 = clk0;
+            hb->clk1 = wall_clock64();
+            __threadfence_system();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&hb->seq, cc.hb_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

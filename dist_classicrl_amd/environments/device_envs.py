@@ -33,6 +33,7 @@ class DeviceVecEnv:
         self._h = C.c_void_p()
         self._algo = None
         self._lib = None
+        self._resident = None  # (states array, rewards array) of the state dict that mirrors the device
 
     def __len__(self) -> int:
         return self.num_agents
@@ -61,6 +62,7 @@ class DeviceVecEnv:
             )
             raise ValueError(msg)
         self.close()
+        self._resident = None
         self._lib = _lib.load()
         _lib.check(self._lib.qe_env_create(C.byref(self._h), algorithm.handle, self.num_agents,
                                            C.byref(self._params)))
@@ -87,23 +89,68 @@ class DeviceVecEnv:
                                             _lib.ptr(acc, C.c_float)))
         return self._wrap(obs, masks), acc
 
-    def restore(self, obs=None, agent_rewards=None) -> None:
+    def aux(self) -> np.ndarray:
+        """Environment-internal per-agent state (episode counters, board marks): what an exact resume
+        needs besides observations and running returns."""
         self._need()
+        out = np.empty(self.num_agents, dtype=np.uint32)
+        _lib.check(self._lib.qe_env_aux(self._h, _lib.ptr(out, C.c_uint32)))
+        return out
+
+    def state_dict(self) -> dict:
+        """The resume dict of ``SingleThreadQLearning.run_steps`` (single_thread_runtime.py:70-75) for
+        the current device state, plus ``"aux"``.  Its arrays are read-only: as long as the caller hands
+        this very dict (or these very arrays) back, :meth:`is_resident` recognises it and nothing is
+        copied to the device."""
+        states, rewards = self.observe()
+        aux = self.aux()
+        obs = states["observation"] if isinstance(states, dict) else states
+        for arr in (obs, rewards, aux):
+            arr.flags.writeable = False
+        self._resident = (obs, rewards)
+        return {"states": states, "infos": [{}] * self.num_agents, "rewards": rewards, "aux": aux}
+
+    def is_resident(self, state_dict) -> bool:
+        """True if ``state_dict`` is the (unmodified) one :meth:`state_dict` produced last and the device
+        state has not been touched since."""
+        if self._resident is None:
+            return False
+        states = state_dict.get("states")
+        obs = states.get("observation") if isinstance(states, dict) else states
+        rewards = state_dict.get("rewards")
+        return (obs is self._resident[0] and rewards is self._resident[1]
+                and not obs.flags.writeable and not rewards.flags.writeable)
+
+    def restore(self, obs=None, agent_rewards=None, aux=None) -> None:
+        self._need()
+        self._resident = None
         if isinstance(obs, dict):
             obs = obs["observation"]
         o = None if obs is None else _lib.as_i32(obs)
         r = None if agent_rewards is None else np.ascontiguousarray(agent_rewards, dtype=np.float32)
-        _lib.check(self._lib.qe_env_restore(self._h, _lib.ptr(o, C.c_int32), None, _lib.ptr(r, C.c_float)))
+        x = None if aux is None else np.ascontiguousarray(aux, dtype=np.uint32)
+        for arr in (o, r, x):
+            if arr is not None and arr.size != self.num_agents:
+                msg = f"expected {self.num_agents} entries, got {arr.size}"
+                raise ValueError(msg)
+        _lib.check(self._lib.qe_env_restore(self._h, _lib.ptr(o, C.c_int32), _lib.ptr(x, C.c_uint32),
+                                            _lib.ptr(r, C.c_float)))
 
-    def reset(self, seed=None, options=None):  # noqa: ARG002
+    def reset_device(self, seed=None) -> None:
+        """``reset`` without fetching the observations (the fused rollout does not need them)."""
         self._need()
+        self._resident = None
         _lib.check(self._lib.qe_env_reset(self._h, 0 if seed is None else 1,
                                           0 if seed is None else int(seed) & 0xFFFFFFFF))
+
+    def reset(self, seed=None, options=None):  # noqa: ARG002
+        self.reset_device(seed)
         obs, _ = self.observe()
         return obs, [{}] * self.num_agents
 
     def step(self, actions):
         self._need()
+        self._resident = None
         a = _lib.as_i32(actions).ravel()
         if a.size != self.num_agents:
             msg = f"expected {self.num_agents} actions, got {a.size}"

@@ -80,6 +80,7 @@ typedef struct qe_rollout_stats {
     double dominant_ms;      /* summed HIP-event time of the sampled dominant-kernel launches */
     int64_t dominant_launches; /* how many launches were sampled (<= 256, spread over the call) */
     int64_t dominant_env_steps; /* env-steps (agent x vector step) those sampled launches processed */
+    double device_clock_ms;  /* persistent path: in-kernel constant-rate clock, launch start -> results published (0 otherwise) */
 } qe_rollout_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -98,7 +99,12 @@ int qe_set_stream(qe_engine* e, void* hip_stream);
  * lanes_per_row <= 1024), 3 = step-wise with chip-wide token rounds for the ordered path ("wide"). */
 enum qe_option { QE_OPT_ROLLOUT_PATH = 0, QE_OPT_USE_GRAPH = 1 /* 1 (default): replay the step-wise kernels from a HIP graph */,
                  QE_OPT_TOKEN_ROUNDS = 2 /* wide mode: chip-wide rounds per step; 0 (default) = chosen from the previous call */,
-                 QE_OPT_LISTED_MIN_AGENTS = 3 /* wide mode: agent count from which the rounds walk compacted lists (default 16384) */ };
+                 QE_OPT_LISTED_MIN_AGENTS = 3 /* wide mode: agent count from which the rounds walk compacted lists (default 16384) */,
+                 QE_OPT_EVENT_TIMING = 4 /* 1 (default): bracket every rollout with HIP events (kernel_ms); 0: persistent rollouts
+                                            report the in-kernel clock only and put no event into the stream */,
+                 QE_OPT_HOST_BLOCK = 5 /* 1 (default): a persistent rollout writes its results (control words, final observations,
+                                          episode log) into page-locked host memory itself and qe_rollout_end spins on a sequence
+                                          word there; 0: stream synchronisation + copies */ };
 int qe_set_option(qe_engine* e, int32_t option, int64_t value);
 
 /* ---- Q-table I/O ----------------------------------------------------------------------------
@@ -166,6 +172,10 @@ int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, cons
 int qe_rollout_begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
                      int32_t mode, int32_t slot);
 int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats);
+/* Largest `steps` of one qe_rollout / qe_rollout_begin / qe_evaluate call on this environment for which
+ * the episode log cannot overflow even if every agent finishes an episode in every step (the caller
+ * chops longer calls: single_thread_runtime.py:63-64 has no such limit). */
+int64_t qe_rollout_chunk_limit(qe_engine* e, qe_env* env, int32_t learn);
 /* Schedule plan: the eps[t] / lr[t] values of a whole training call (same meaning as in qe_rollout),
  * uploaded once.  Afterwards qe_rollout_begin may be called with eps == NULL and lr == NULL: each
  * such call consumes the next `steps` values of the plan, so a call chopped into many short rollouts

@@ -32,7 +32,7 @@ def test_struct_layouts_match_the_header():
     from dist_classicrl_amd import _lib
 
     assert ctypes.sizeof(_lib.EnvParams) == 32
-    assert ctypes.sizeof(_lib.RolloutStats) == 64
+    assert ctypes.sizeof(_lib.RolloutStats) == 72
 
 
 def test_no_cpu_fallback():

@@ -1,22 +1,37 @@
-"""Diagnostic: where the fixed cost of a short `run_steps` call goes (host side)."""
+"""Diagnostic: where the fixed cost of a short `run_steps` call goes (host side).
+
+    python tools/call_overhead.py [steps] [event_timing 0|1] [host_block 0|1]
+"""
 import cProfile, io, pstats, sys, time
 sys.path.insert(0, ".")
 import numpy as np
+from dist_classicrl_amd import _lib
 from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
 from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
 from dist_classicrl_amd.environments import HashTabularEnv
 from dist_classicrl_amd.schedules import ExponentialSchedule
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+timing = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+host_block = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 algo = OptimalQLearningBase(1_000_000, 16, 0.99, seed=0)
+algo.set_engine_option(_lib.OPT_EVENT_TIMING, timing)
+algo.set_engine_option(_lib.OPT_HOST_BLOCK, host_block)
 env = HashTabularEnv(128, 1_000_000, 16, seed=1)
 rt = GpuRolloutQLearning(algo, ExponentialSchedule(0.1, 1e-5, 0.995), ExponentialSchedule(1.0, 0.01, 0.995))
 _, _, _, sd = rt.run_steps(2000, env, None)
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+reps = 300
+dev = 0.0
 t0 = time.perf_counter()
-for _ in range(300):
+for _ in range(reps):
     _, _, _, sd = rt.run_steps(steps, env, sd)
-print(f"{(time.perf_counter() - t0) / 300 * 1e6:.1f} us per run_steps({steps}) call")
-pr = cProfile.Profile(); pr.enable()
-for _ in range(300):
-    _, _, _, sd = rt.run_steps(steps, env, sd)
-pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(14); print(s.getvalue())
+    dev += rt.last_stats["device_clock_ms"] if host_block else rt.last_stats["kernel_ms"]
+per = (time.perf_counter() - t0) / reps * 1e6
+print(f"steps={steps} event_timing={timing} host_block={host_block}: {per:.1f} us per run_steps call, "
+      f"{dev / reps * 1e3:.1f} us of it on the device ({dev / reps * 1e3 / steps:.2f} us/step) -> "
+      f"{per - dev / reps * 1e3:.1f} us fixed; {steps * 128 / per:.1f} M env-steps/s")
+if len(sys.argv) > 4:
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(reps):
+        _, _, _, sd = rt.run_steps(steps, env, sd)
+    pr.disable()
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(16); print(s.getvalue())
