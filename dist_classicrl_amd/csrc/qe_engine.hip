@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "qe_kernels.h"
+#include "qe_rollout_lane.h"
 
 using namespace qe;
 
@@ -111,6 +112,15 @@ void sort_episode_log(std::vector<std::pair<unsigned long long, float>>& v,
         std::swap(src, dst);
     }
     if (src != &v) v.swap(tmp);
+}
+
+// Row stride in elements: a power of two (4 .. 64) up to 64 actions -- a lane of the persistent kernel
+// holds a whole row and loads all of it unconditionally -- else the action count rounded up to 4.
+int row_stride(int A) {
+    if (A > 64) return (A + 3) / 4 * 4;
+    int ld = 4;
+    while (ld < A) ld <<= 1;
+    return ld;
 }
 
 int lanes_per_row(int ld) {  // smallest power of two L with 4*L >= ld
@@ -359,9 +369,9 @@ static int slot_host_block(qe_engine* e, RolloutSlot& sl, size_t agents) {
     return QE_OK;
 }
 
+// one launch per rollout on one CU, one agent per lane with its whole row in registers (qe_rollout_lane.h)
 static bool persistent_path(const qe_engine* e, const qe_env* env, int learn) {
-    return learn && env->N * e->L <= PERSIST_MAX_LANES && env->N <= PERSIST_MAX_AGENTS &&
-           (e->opt_path == 0 || e->opt_path == 2);
+    return learn && env->N <= LANE_MAX_AGENTS && e->ld <= 64 && (e->opt_path == 0 || e->opt_path == 2);
 }
 
 int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps, const double* lr, bool use_plan,
@@ -523,11 +533,10 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     if (e->dlog && learn) {
         c.dlog = e->dlog; c.dlog_base = e->dlog_count; c.dlog_cap = e->dlog_cap;
     }
-    const int64_t lanes = env->N * e->L;
     const bool persistent = persistent_path(e, env, learn);
     if (learn && e->opt_path == 2 && !persistent)
-        return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and num_agents * lanes_per_row <= 1024 (have %lld lanes)",
-                    (long long)lanes);
+        return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and action_size <= 64 (have %lld agents, %d actions)",
+                    (long long)env->N, (int)e->A);
     // wide mode: exact sequential updates, many agents, ordered path spread over the chip
     const bool wide = learn && !persistent &&
                       (e->opt_path == 3 || (e->opt_path == 0 && env->N >= 2048));
@@ -566,39 +575,41 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     if (sl.fast && !e->opt_timing) sl.timed = false;  // in-kernel clock only
     if (sl.timed) HIP_TRY(hipEventRecord(sl.ev0, e->stream));
     if (persistent) {
-        const unsigned block = (unsigned)((lanes + 63) / 64 * 64);
-        auto go = [&](auto lc) {
-            constexpr int LCV = decltype(lc)::value;
-            // up to 512 threads the kernel is built with twice the vector-register budget (the BASELINE
-            // shapes with 128 agents: 256 or 512 lanes)
-            constexpr int SMALL = (LCV == 2 || LCV == 4) ? 512 : 1024;
-            const bool lean = mode == QE_LEARN_ITER && !c.trace;
-            if ((LCV == 2 || LCV == 4) && block <= 512 && lean && !c.dlog)
-                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL, SMALL == 512 ? 1 : 0>), dim3(1),
-                                   dim3(block), 0, e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-            else if ((LCV == 2 || LCV == 4) && block <= 512 && lean)
-                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL, SMALL == 512 ? 2 : 0>), dim3(1),
-                                   dim3(block), 0, e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-            else if ((LCV == 2 || LCV == 4) && block <= 512)
-                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, SMALL>), dim3(1),
-                                   dim3(block), 0, e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+        const unsigned block = (unsigned)((env->N + 63) / 64 * 64);
+        const bool lean = mode == QE_LEARN_ITER && !c.trace;
+        auto go = [&](auto nv, auto masked) {
+            constexpr int NV = decltype(nv)::value;
+            constexpr bool MK = decltype(masked)::value;
+            // the BASELINE shapes with up to 128 agents (two wavefronts) get builds that know they are plain
+            // training rollouts (LEAN, see the kernel) and may use the whole register file
+            constexpr bool HAS_LEAN = std::is_same<T, float>::value &&
+                                      ((std::is_same<Env, HashEnv>::value && !MK && (NV == 2 || NV == 4)) ||
+                                       std::is_same<Env, TttEnv>::value);
+            if (HAS_LEAN && lean && block <= 128 && !c.dlog)
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0>), dim3(1), dim3(block), 0, e->stream,
+                                   sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+            else if (HAS_LEAN && lean && block <= 128)
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0>), dim3(1), dim3(block), 0, e->stream,
+                                   sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else
-                hipLaunchKernelGGL((k_rollout_persistent<T, Env, LCV, 1024>), dim3(1), dim3(block), 0,
-                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, LANE_MAX_AGENTS, MK, 0>), dim3(1), dim3(block), 0, e->stream,
+                                   sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
         };
+        using Yes = std::true_type;
+        using No = std::false_type;
         if constexpr (std::is_same<Env, HashEnv>::value) {
-            switch (e->L) {  // compile-time lane-group width: reductions become DPP moves
-                case 1: go(std::integral_constant<int, 1>{}); break;
-                case 2: go(std::integral_constant<int, 2>{}); break;
-                case 4: go(std::integral_constant<int, 4>{}); break;
-                case 8: go(std::integral_constant<int, 8>{}); break;
-                case 16: go(std::integral_constant<int, 16>{}); break;
-                default: go(std::integral_constant<int, 0>{}); break;
+            auto by_mask = [&](auto nv) { if (env->p.masked) go(nv, Yes{}); else go(nv, No{}); };
+            switch (e->ld) {  // a power of two (row_stride)
+                case 4: by_mask(std::integral_constant<int, 1>{}); break;
+                case 8: by_mask(std::integral_constant<int, 2>{}); break;
+                case 16: by_mask(std::integral_constant<int, 4>{}); break;
+                case 32: by_mask(std::integral_constant<int, 8>{}); break;
+                default: by_mask(std::integral_constant<int, 16>{}); break;
             }
         } else if constexpr (std::is_same<Env, TttEnv>::value) {
-            go(std::integral_constant<int, 4>{});  // A = 9 -> ld = 12 -> 4 lanes per row
+            go(std::integral_constant<int, 4>{}, Yes{});  // A = 9 -> row stride 16
         } else {
-            go(std::integral_constant<int, 1>{});  // GridLake (A = 4) and the bandit (A = 2): one lane per row
+            go(std::integral_constant<int, 1>{}, No{});  // GridLake (A = 4) and the bandit (A = 2)
         }
         ++sl.launches;
     } else if (learn) {
@@ -855,8 +866,8 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     *out = nullptr;
     if (S <= 0 || A <= 0) return fail(QE_ERR_INVALID, "state_size and action_size must be positive");
     if (dtype != QE_F32 && dtype != QE_F64) return fail(QE_ERR_INVALID, "dtype must be QE_F32 or QE_F64");
-    if ((double)S * ((A + 3) / 4 * 4) >= 4294967296.0)
-        return fail(QE_ERR_UNSUPPORTED, "state_size * padded action_size must be < 2^32 cells");
+    if ((double)S * row_stride(A) >= 4294967296.0)
+        return fail(QE_ERR_UNSUPPORTED, "state_size * padded action_size (%d) must be < 2^32 cells", row_stride(A));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(QE_ERR_NO_DEVICE, "no HIP device visible: the Q-learning engine has no CPU fallback");
@@ -868,7 +879,7 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
             e->wall_clock_khz = (double)khz;
     }
-    e->device = device; e->dtype = dtype; e->S = S; e->A = A; e->ld = (A + 3) / 4 * 4;
+    e->device = device; e->dtype = dtype; e->S = S; e->A = A; e->ld = row_stride(A);
     e->L = lanes_per_row(e->ld);
     if (e->L > 64) e->L = 64;  // A > 256: the wave-per-row kernels take over
     for (e->lshift = 0; (1 << e->lshift) < e->L; ++e->lshift) {}
@@ -888,6 +899,14 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = hipMemsetAsync(e->q, 0, bytes, e->stream);
+    if (err == hipSuccess && e->ld > e->A) {  // padding columns hold -inf (see load_row_lane)
+        const int64_t cells = S * (int64_t)(e->ld - e->A);
+        if (dtype == QE_F32)
+            hipLaunchKernelGGL(k_pad_fill<float>, dim3(grid_for(cells, 256)), dim3(256), 0, e->stream, (float*)e->q, S, e->A, e->ld);
+        else
+            hipLaunchKernelGGL(k_pad_fill<double>, dim3(grid_for(cells, 256)), dim3(256), 0, e->stream, (double*)e->q, S, e->A, e->ld);
+        err = hipGetLastError();
+    }
     if (err == hipSuccess) err = hipMemsetAsync(e->stamps, 0, (size_t)S * 2 * sizeof(unsigned long long), e->stream);
     if (err == hipSuccess) err = hipMemsetAsync(e->ctrl, 0, sizeof(Ctrl), e->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);

@@ -605,9 +605,10 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
             const bool prestaged = (flags & FLAG_PRESTAGED) != 0;
             int64_t i;
             LiveAgent<T> g;
-            if (prestaged) {  // written straight from the owners' registers (persistent kernel)
-                i = lds.a_agent[pos];
-                g.s = lds.a_s[pos]; g.a = lds.a_a[pos]; g.n = lds.a_n[pos]; g.r = lds.a_r[pos]; g.term = lds.a_term[pos] != 0;
+            if (prestaged) {  // written straight from the owners' registers (persistent kernel), whole list
+                const int at = base + pos;
+                i = lds.a_agent[at];
+                g.s = lds.a_s[at]; g.a = lds.a_a[at]; g.n = lds.a_n[at]; g.r = lds.a_r[at]; g.term = lds.a_term[at] != 0;
             } else {
                 // (the mirror is indexed by list position; staging only ever rewrites its first B entries,
                 // with the batch that has just read them)
@@ -637,7 +638,9 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
             if ((id & 1) == 0) {
                 lds.a_state[pos] = 0;
                 lds.a_mready[pos] = 0;
-                if (!prestaged) {
+                // (a later batch of a prestaged list moves down to the front: entries < B are written, entries
+                // >= base >= B are read)
+                if (!prestaged || base) {
                     lds.a_agent[pos] = (int)i; lds.a_s[pos] = g.s; lds.a_a[pos] = g.a; lds.a_n[pos] = g.n;
                     lds.a_r[pos] = g.r; lds.a_term[pos] = g.term ? 1 : 0;
                 }
@@ -1739,6 +1742,15 @@ __global__ void k_env_masks(EnvCtx ev, int64_t N, const int32_t* obs, uint8_t* m
 }
 
 // ---- table helpers ----------------------------------------------------------------------------
+// padding columns A .. ld-1 of every row <- -inf (never a maximum, never tied with one)
+template <typename T>
+__global__ void k_pad_fill(T* q, int64_t S, int A, int ld) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int pad = ld - A;
+    if (k >= S * pad) return;
+    q[(k / pad) * ld + A + (k % pad)] = neg_inf<T>();
+}
+
 template <typename T>
 __global__ void k_cells(T* q, int ld, const int32_t* s, const int32_t* a, int64_t n, double* vals, int op) {
     // op 0 read, 1 write: one thread per cell; op 2 (np.add.at): one thread, index order

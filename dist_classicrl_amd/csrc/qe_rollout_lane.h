@@ -1,0 +1,557 @@
+// qe_rollout_lane.h -- persistent rollout, ONE AGENT PER LANE (gfx950, wave64).
+//
+// The whole `steps`-step training loop of up to 512 agents (rows of up to 64 actions) in one launch on
+// one CU, like k_rollout_persistent (qe_kernels.h), but every lane owns a whole agent: its Q-row
+// (4*NV values from NV 16-byte loads) sits in the lane's registers, arg-max / tie count / k-th tie /
+// picked value are computed in-lane with no cross-lane traffic at all.  128 agents are then TWO
+// wavefronts (one per SIMD) instead of eight: a quarter of the vector issue, no DPP chains, and a
+// workgroup barrier between two waves instead of eight (measured on the 128-agent headline shape with
+// the 4-lanes-per-row kernel: select + env.step 0.71 us, barrier wait 0.44 us, LDS touch inserts 0.35 us
+// of a 2.5 us step).
+//
+// Exactness is inherited from the step structure of k_rollout_persistent, unchanged:
+//   * touches of step t (W(row s), R(row n)) go into one of three rotating LDS hash tables before the
+//     step's barrier; a slot is ONE 64-bit word {row + 1, writers, readers}, so the usual case -- first
+//     toucher of the row -- is a single compare-and-swap round trip;
+//   * quiet step (no row with two touchers): row gather -> TD update of Q[s,a] -> selection of the next
+//     action from the same registers (own write patched in) -> env.step;
+//   * busy step: on every contested row the lowest-indexed toucher proceeds at once, the others follow in
+//     index order -- in place when every contested row has two touchers, through slow_body (the ordered
+//     path of qe_kernels.h, which brings its own lane-group view of the rows) otherwise; an agent whose
+//     next-state row is written by someone else selects after all updates of the step.
+// learn_vec (np.add.at order) takes the same route with the batch path of slow_body.
+#pragma once
+#include "qe_kernels.h"
+
+namespace qe {
+
+constexpr int LANE_MAX_AGENTS = 512;
+constexpr int LANE_CT_SLOTS = 2048;  // >= 2 x touches per step (two per agent)
+
+template <typename T, int NV>
+struct RowV {
+    T v[4 * NV];
+};
+
+template <int NV>
+struct LaneMask {
+    using type = uint32_t;
+};
+template <>
+struct LaneMask<16> {
+    using type = uint64_t;
+};
+
+__device__ __forceinline__ int popc_mask(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ int popc_mask(uint64_t x) { return __popcll(x); }
+
+// whole row of one agent: NV loads of 16 bytes (fp32) / 2 x 16 bytes (fp64).  The row stride is exactly
+// 4 * NV elements (power-of-two strides up to 64 actions, qe_create) and the padding columns of the
+// table hold -inf, so no column needs a guard: padding never wins a maximum and never ties with one.
+template <int NV>
+__device__ __forceinline__ void load_row_lane(RowV<float, NV>& r, const float* q, int64_t row) {
+    const float4* p = reinterpret_cast<const float4*>(q + row * (4 * NV));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const float4 f = p[k];
+        r.v[4 * k] = f.x; r.v[4 * k + 1] = f.y; r.v[4 * k + 2] = f.z; r.v[4 * k + 3] = f.w;
+    }
+}
+template <int NV>
+__device__ __forceinline__ void load_row_lane(RowV<double, NV>& r, const double* q, int64_t row) {
+    const double2* p = reinterpret_cast<const double2*>(q + row * (4 * NV));
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double2 a = p[2 * k], b = p[2 * k + 1];
+        r.v[4 * k] = a.x; r.v[4 * k + 1] = a.y; r.v[4 * k + 2] = b.x; r.v[4 * k + 3] = b.y;
+    }
+}
+
+__device__ __forceinline__ float lane_fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double lane_fmax(double a, double b) { return __builtin_fmax(a, b); }
+
+// Masked environments: the row with every invalid column replaced by -inf (what the reference's
+// np.where(mask, q, -inf) builds, q_learning_optimal.py:464-466); unmasked ones use the row as loaded.
+template <bool MASKED, typename T, int NV, typename M>
+__device__ __forceinline__ RowV<T, NV> masked_row(const RowV<T, NV>& row, M valid) {
+    if constexpr (!MASKED) {
+        return row;
+    } else {
+        RowV<T, NV> r;
+#pragma unroll
+        for (int j = 0; j < 4 * NV; ++j) r.v[j] = ((valid >> j) & 1) ? row.v[j] : neg_inf<T>();
+        return r;
+    }
+}
+
+// maximum over a (masked) row; -inf if no column is valid.  maxNum ignores a NaN operand, exactly like
+// the `v > m ? v : m` scans of qe_device.h.
+template <typename T, int NV>
+__device__ __forceinline__ T row_max_lane(const RowV<T, NV>& rowm) {
+    T m = neg_inf<T>();
+#pragma unroll
+    for (int j = 0; j < 4 * NV; ++j) m = lane_fmax(m, rowm.v[j]);
+    return m;
+}
+
+// value of column `idx` (0 <= idx < 4 * NV): a binary tree of selects over scalars (log2 levels, one
+// select per node) instead of a dynamically indexed register array.  Every node is made opaque to the
+// optimiser, which otherwise folds the tree back into ONE variable-index extract and lowers that as a
+// compare-and-select chain over all columns (15 chains of 16 at 16 columns).
+template <typename T, int NV, int LO, int CNT>
+__device__ __forceinline__ T row_pick_tree(const RowV<T, NV>& row, int idx) {
+    constexpr int W = 4 * NV;
+    if constexpr (CNT == 1) {
+        T x = row.v[LO < W ? LO : W - 1];
+        asm volatile("" : "+v"(x));
+        return x;
+    } else {
+        const T lo = row_pick_tree<T, NV, LO, CNT / 2>(row, idx);
+        const T hi = row_pick_tree<T, NV, LO + CNT / 2, CNT / 2>(row, idx);
+        T r = (idx & (CNT / 2)) ? hi : lo;
+        asm volatile("" : "+v"(r));
+        return r;
+    }
+}
+template <typename T, int NV>
+__device__ __forceinline__ T row_pick_lane(const RowV<T, NV>& row, int idx) {
+    constexpr int W = 4 * NV;
+    constexpr int P = W <= 4 ? 4 : (W <= 8 ? 8 : (W <= 16 ? 16 : (W <= 32 ? 32 : 64)));
+    return row_pick_tree<T, NV, 0, P>(row, idx);
+}
+
+// position of the k-th (0-based) set bit of f, k < popcount(f): branch-free binary search
+template <int NV, typename M>
+__device__ __forceinline__ int kth_set_bit(M f, int k) {
+    constexpr int W = 4 * NV;
+    constexpr int P = W <= 4 ? 4 : (W <= 8 ? 8 : (W <= 16 ? 16 : (W <= 32 ? 32 : 64)));
+    constexpr int LOG = P == 4 ? 2 : (P == 8 ? 3 : (P == 16 ? 4 : (P == 32 ? 5 : 6)));
+    int pos = 0;
+#pragma unroll
+    for (int lv = 0; lv < LOG; ++lv) {
+        const int width = P >> (lv + 1);
+        const M low = f & (((M)1 << width) - 1);
+        const int c = popc_mask(low);
+        const bool hi = k >= c;
+        k -= hi ? c : 0;
+        f = hi ? (f >> width) : low;
+        pos += hi ? width : 0;
+    }
+    return pos;
+}
+
+// Epsilon-greedy pick from a row held by one lane; same distribution and draw use as select_action
+// (qe_device.h): explore -> k-th valid action, k = mulhi(x1, n_valid); greedy -> k-th action tied at the
+// valid maximum, k = mulhi(x2, n_ties).  Returns -1 when no action is selectable.  `rowm` = masked_row.
+template <typename T, int NV, typename M>
+__device__ __forceinline__ int select_lane(const RowV<T, NV>& rowm, M valid, bool explore, uint32_t x1,
+                                           uint32_t x2, T* picked) {
+    const T m = row_max_lane(rowm);
+    M ties = 0;
+#pragma unroll
+    for (int j = 0; j < 4 * NV; ++j) ties |= (M)(rowm.v[j] == m ? 1u : 0u) << j;
+    const M f = explore ? valid : (ties & valid);  // (& valid: with no finite candidate -inf ties everywhere)
+    const int total = popc_mask(f);
+    int act = -1;
+    if (total > 0) act = kth_set_bit<NV>(f, (int)mulhi32(explore ? x1 : x2, (uint32_t)total));
+    *picked = row_pick_lane(rowm, act < 0 ? 0 : act);  // a selectable column is valid: rowm holds its Q-value
+    return act;
+}
+
+// validity of the columns of the row of `obs` as a bit mask.  Unmasked environments: the columns below
+// A, a launch constant.
+template <class Env, int NV, bool MASKED>
+__device__ __forceinline__ typename LaneMask<NV>::type valid_mask_lane(const EnvCtx& ev, int64_t i, int32_t obs) {
+    using M = typename LaneMask<NV>::type;
+    if constexpr (!MASKED) {
+        return ev.A >= 8 * (int)sizeof(M) ? ~(M)0 : (((M)1 << ev.A) - 1);
+    } else {
+        M m = 0;
+#pragma unroll
+        for (int sub = 0; sub < NV; ++sub) m |= (M)Env::valid4(ev, i, obs, sub) << (4 * sub);
+        return m;
+    }
+}
+
+template <int CAP>
+struct LaneLds {
+    SlowLdsT<CAP, PERSIST_CACHE_BYTES> slow;
+    unsigned long long ct[3][LANE_CT_SLOTS];  // (row + 1) << 32 | writers << 16 | readers; 0 = free
+    int ct_min[3][LANE_CT_SLOTS];             // lowest toucher index
+    unsigned long long ep_key[EP_STAGE];
+    float ep_ret[EP_STAGE];
+    unsigned char pending[CAP];   // 1 while an agent's deferred update is outstanding
+    alignas(16) unsigned char cold[384];  // the launch context, for the rare paths
+    unsigned def_bits[CAP / 32];  // deferred agents of a step (general ordered path), by index
+    unsigned busy[3];             // step t: some row has more than one toucher
+    unsigned ep_n;
+    unsigned n_def;       // agents whose update is deferred in this step
+    unsigned complex_;    // a contested row has more than two touchers
+};
+
+// Registers a touch of `row` in table `tb`: one 64-bit compare-and-swap when this agent is the row's
+// first toucher of the step; a second toucher adds its count (and raises the step's busy flag).
+template <int CAP>
+__device__ __forceinline__ int lane_touch(LaneLds<CAP>& l, int tb, int32_t row, unsigned kind, int agent) {
+    const unsigned long long key = (unsigned long long)((uint32_t)row + 1u) << 32;
+    int h = (int)(mix32((uint32_t)row) & (LANE_CT_SLOTS - 1));
+    for (;;) {
+        const unsigned long long old = atomicCAS(&l.ct[tb][h], 0ull, key | kind);
+        if (old == 0ull) break;
+        if ((old >> 32) == (key >> 32)) {
+            atomicAdd(&l.ct[tb][h], (unsigned long long)kind);
+            l.busy[tb] = 1u;
+            break;
+        }
+        h = (h + 1) & (LANE_CT_SLOTS - 1);
+    }
+    atomicMin(&l.ct_min[tb][h], agent);
+    return h;
+}
+
+#ifdef QE_STAMPS
+#define QL_STAMP(k) do { const long long _n = wall_clock64(); stamp_sum[k] += _n - stamp_last; stamp_last = _n; } while (0)
+#else
+#define QL_STAMP(k) do { } while (0)
+#endif
+
+// LEAN: 1 = plain training rollout (sequential learn, no action trace, no delta log), 2 = the same with
+// the delta log of the replica exchange; known at compile time, which drops their uniform branches
+// and operands from the loop.
+template <typename T, class Env, int NV, int CAP, bool MASKED, int LEAN = 0>
+__global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 of the kernarg segment*/,
+                                                      Ctx<T> c, EnvCtx ev, long long steps, int flags) {
+    using M = typename LaneMask<NV>::type;
+    __shared__ LaneLds<CAP> lds;
+    const unsigned long long clk0 = wall_clock64();
+    if (c.thr == nullptr) {  // short rollout: the schedule values came with the launch
+        const QE_AS4 unsigned char* ka = (const QE_AS4 unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
+        c.thr = (const QE_AS4 unsigned long long*)ka;
+        c.lr = (const QE_AS4 double*)(ka + sizeof(unsigned long long) * INLINE_SCHED_STEPS);
+    }
+    if constexpr (LEAN != 0) { c.mode = 0; c.trace = nullptr; }
+    if constexpr (LEAN == 1) c.dlog = nullptr;
+#ifdef QE_STAMPS
+    long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_last = wall_clock64();
+    if (threadIdx.x == 0) for (int k = 8; k < 24; ++k) c.vinc[k] = 0.0;
+#endif
+    const int tid = threadIdx.x;
+    const int i = tid;
+    const bool active = i < c.N;
+    const int ii = active ? i : 0;
+    Pending<T> p;
+    p.n = c.n[ii];
+    p.aux = c.aux[ii];
+    p.s = 0; p.a = 0; p.pred = 0; p.r = 0.0f; p.term = false;
+    float acc = c.acc[ii];
+    unsigned long long deferred_total = 0, ep_base = 0;
+    int cur_s = -1, cur_n = -1, prev_s = -1, prev_n = -1;  // my slots of steps t-1 / t-2
+    const int flush_every = 32;  // steps per flush window of the staged episode log
+    int flush_in = flush_every;
+    for (int k = tid; k < 3 * LANE_CT_SLOTS; k += (int)blockDim.x) {
+        (&lds.ct[0][0])[k] = 0ull;
+        (&lds.ct_min[0][0])[k] = 0x7FFFFFFF;
+    }
+    for (int k = tid; k < CAP; k += (int)blockDim.x) lds.pending[k] = 0;
+    if (tid < CAP / 32) lds.def_bits[tid] = 0u;
+    // what only the rare paths need (agent arrays for the general ordered path, log pointers for the
+    // periodic flush, the epilogue) is parked in LDS and fetched when such a path runs
+    static_assert(sizeof(Ctx<T>) <= sizeof(lds.cold), "context stash too small");
+    if (tid == 0) {
+        *reinterpret_cast<Ctx<T>*>(lds.cold) = c;
+        lds.ep_n = 0u; lds.n_def = 0u; lds.complex_ = 0u;
+        lds.busy[0] = lds.busy[1] = lds.busy[2] = 0u;
+        c.ctrl->error = 0u;  // this launch owns the control block: no host-side memset in front of it
+        c.ctrl->inv_count = 0u;
+    }
+    __syncthreads();  // the control block is initialised before any wave may report through it
+
+    // selection + env.step of step t1 from `row` (= Q[p.n]); the new pending transition replaces p
+    auto advance = [&](const RowV<T, NV>& row, M valid, long long t1, const U4& x) {
+        const bool explore = (unsigned long long)x.x < c.thr[t1];
+        T picked;
+        int act = select_lane<T, NV, M>(masked_row<MASKED>(row, valid), valid, explore, x.y, x.z, &picked);
+        if (act < 0) {
+            // no selectable action (everything masked, or a NaN row maximum): the reference's
+            // random.choice raises IndexError (q_learning_optimal.py:470,563); reported at the end of the
+            // call, action 0 keeps the rest of the rollout inside the table
+            c.ctrl->error = ERR_EMPTY_CHOICE;
+            act = 0;
+        }
+        const int32_t n = p.n;
+        const Transition tr = Env::step(ev, i, n, p.aux, act, c.step0 + (unsigned long long)t1);
+        if (c.trace) c.trace[t1 * c.N + i] = act;
+        p.s = n; p.a = act; p.pred = picked; p.r = tr.reward; p.term = tr.terminated; p.n = tr.next_obs;
+    };
+    auto draws = [&](long long t1) {
+        const unsigned long long step1 = c.step0 + (unsigned long long)t1;
+        return philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)step1, (uint32_t)(step1 >> 32), STREAM_POLICY,
+                             c.seed_lo, c.seed_hi);
+    };
+
+    {   // select(0), env.step(0)
+        RowV<T, NV> row;
+        load_row_lane<NV>(row, c.q, p.n);
+        if (active) advance(row, valid_mask_lane<Env, NV, MASKED>(ev, i, p.n), 0, draws(0));
+    }
+    __syncthreads();
+    int tb = 0;  // t % 3
+    DeltaEntry* dl = c.dlog ? c.dlog + c.dlog_base + ii : nullptr;  // this agent's record of step 0
+    const long long dl_steps = c.dlog ? (c.dlog_cap - c.dlog_base) / c.N : 0;  // steps whose records all fit
+    for (long long t = 0; t < steps; ++t) {
+        const bool last = t + 1 == steps;
+        const bool dl_ok = t < dl_steps;
+        const int tb_old = tb == 2 ? 0 : tb + 1;  // (t - 2) % 3 == (t + 1) % 3: retired two barriers ago
+        QL_STAMP(7);
+        // ---- register this step's touches (W(s), R(n)); retire my entries of step t-2 -----------
+        if (active) {
+            if (prev_s >= 0) { lds.ct[tb_old][prev_s] = 0ull; lds.ct_min[tb_old][prev_s] = 0x7FFFFFFF; }
+            if (prev_n >= 0) { lds.ct[tb_old][prev_n] = 0ull; lds.ct_min[tb_old][prev_n] = 0x7FFFFFFF; }
+            prev_s = cur_s; prev_n = cur_n;
+            cur_s = lane_touch(lds, tb, p.s, 1u << 16, i);
+            cur_n = p.n != p.s ? lane_touch(lds, tb, p.n, 1u, i) : -1;
+        }
+        if (tid == 0) lds.busy[tb_old] = 0u;
+        QL_STAMP(0);
+        __syncthreads();  // every table write of step t-1 is complete; touches of step t are in
+        QL_STAMP(1);
+        const bool busy = lds.busy[tb] != 0u;
+        RowV<T, NV> row;
+        load_row_lane<NV>(row, c.q, p.n);  // the one row gather of a quiet step
+        const M valid = valid_mask_lane<Env, NV, MASKED>(ev, ii, p.n);
+        // ---- classification (only when some row has several touchers) ---------------------------
+        int cls = 3;  // bit0: update now, bit1: select now
+        int pred_s = -1, pred_n = -1;
+        if (busy && active) {
+            const unsigned long long ws = lds.ct[tb][cur_s];
+            const unsigned cs = (unsigned)ws;
+            const int ms = lds.ct_min[tb][cur_s];
+            unsigned cn = 0u;
+            int mn = 0x7FFFFFFF;
+            const bool has_n = cur_n >= 0;
+            if (has_n) { cn = (unsigned)lds.ct[tb][cur_n]; mn = lds.ct_min[tb][cur_n]; }
+            const unsigned w_s = cs >> 16, tot_s = w_s + (cs & 0xFFFFu);
+            const unsigned w_n = cn >> 16, tot_n = w_n + (cn & 0xFFFFu);
+            bool now = true, sel = true, cx = false;
+            if (c.mode == 1) {
+                // VEC (learn_vec): every toucher of a row that is written AND shared reads the
+                // pre-step table, so all of them go through the batch path together
+                const bool shared = w_s >= 2u || (w_s == 1u && tot_s >= 2u) || (has_n && w_n >= 1u && tot_n >= 2u);
+                if (shared) { now = false; cx = true; }
+                sel = !(has_n ? w_n > 0u : w_s > 1u);
+            } else {
+                if (tot_s > 1u && ms < i) { now = false; pred_s = ms; cx |= tot_s > 2u; }
+                if (has_n) {
+                    if (w_n > 0u) {
+                        sel = false;  // someone writes the row my next action is chosen from
+                        if (!p.term && mn < i) { now = false; pred_n = mn; cx |= tot_n > 2u; }
+                    }
+                } else if (w_s > 1u) {
+                    sel = false;  // n == s and another agent writes this row too
+                }
+            }
+            cls = (now ? 1 : 0) | (sel ? 2 : 0);
+            if (!now) {
+                lds.pending[i] = 1;
+                atomicAdd(&lds.n_def, 1u);
+                if (cx) lds.complex_ = 1u;
+            }
+        }
+        QL_STAMP(2);
+        // ---- Philox draws of select(t+1): independent of memory, computed under the row gather ----
+        const U4 x = draws(t + 1);
+        const float r_t = p.r;
+        const bool term_t = p.term;
+        QL_STAMP(3);
+        // ---- update of transition t for agents that may go now ----------------------------------
+        if (active && (cls & 1)) {
+            const T m = row_max_lane(masked_row<MASKED>(row, valid));
+            const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
+            T u;
+            const T q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, c.lr[t]), c.mode, &u);
+            c.q[cell] = q1;
+            // delta log of the replica exchange: a running pointer (slot = base + t * N + agent)
+            if (dl_ok) *dl = DeltaEntry{(uint32_t)cell, (float)u};
+            if (p.n == p.s) {  // own write lands in the row held in registers
+#pragma unroll
+                for (int j = 0; j < 4 * NV; ++j) row.v[j] = j == p.a ? q1 : row.v[j];
+            }
+        }
+        if (active) {  // base_runtime.py:212,218-221 for transition t
+            acc += r_t;
+            if (term_t) {
+                if (flags & FLAG_ACCOUNT) {
+                    // entry k of this flush window lands at log position ep_base + k: through the LDS
+                    // stage normally, straight to memory when more episodes end in one window than the
+                    // stage holds
+                    const unsigned k = atomicAdd(&lds.ep_n, 1u);
+                    const unsigned long long key = ((unsigned long long)t << 32) | (unsigned long long)i;
+                    if (k < (unsigned)EP_STAGE) {
+                        lds.ep_key[k] = key;
+                        lds.ep_ret[k] = acc;
+                    } else {
+                        const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+                        if ((long long)(ep_base + k) < cc.ep_cap) {
+                            cc.ep_key[ep_base + k] = key;
+                            cc.ep_ret[ep_base + k] = acc;
+                        }
+                    }
+                }
+                acc = 0.0f;
+            }
+        }
+        QL_STAMP(4);
+        if (active && cls == 3 && !last) advance(row, valid, t + 1, x);
+        QL_STAMP(5);
+
+        if (busy) {
+            // ---- extended step: ordered updates of the deferred agents, then late selections -----
+#ifdef QE_STAMPS
+            const long long ext_t0 = wall_clock64();
+#endif
+            __syncthreads();
+            const int n_def = (int)lds.n_def;
+#ifdef QE_STAMPS
+            if (tid == 0) { c.vinc[16] += 1.0; if (n_def > 0) c.vinc[17] += 1.0; }
+#endif
+            if (n_def > 0) {
+                deferred_total += (unsigned long long)n_def;
+                if (lds.complex_) {
+                    // general case: hand the deferred transitions to slow_body, which views the rows
+                    // through lane groups of its own (c.L lanes per row)
+                    const Ctx<T>& cold = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+                    Ctx<T> cc = c;
+                    cc.s = cold.s; cc.a = cold.a; cc.n = cold.n; cc.r = cold.r; cc.term = cold.term;
+                    cc.pred = cold.pred; cc.aux = cold.aux; cc.acc = cold.acc;
+                    cc.inv_bitmap = cold.inv_bitmap; cc.inv_list = cold.inv_list; cc.vinc = cold.vinc;
+                    cc.ctrl = cold.ctrl; cc.ep_key = cold.ep_key; cc.ep_ret = cold.ep_ret; cc.ep_cap = cold.ep_cap;
+                    cc.stamps = nullptr; cc.tok = nullptr; cc.adv_bitmap = nullptr; cc.pend_list = nullptr;
+                    const bool mine_def = active && !(cls & 1);
+                    if (c.mode == 0) {
+                        // sequential learn: the deferred transitions go from their owners' registers
+                        // straight into the ordered path's LDS staging area, at the owner's rank among
+                        // the deferred agents (the ordered path works on an index-sorted list)
+                        if (mine_def) atomicOr(&lds.def_bits[i >> 5], 1u << (i & 31));
+                        barrier_lds();
+                        if (mine_def) {
+                            int pos = __popc(lds.def_bits[i >> 5] & ((1u << (i & 31)) - 1u));
+                            for (int w = 0; w < (i >> 5); ++w) pos += __popc(lds.def_bits[w]);
+                            lds.slow.a_agent[pos] = i; lds.slow.a_s[pos] = p.s; lds.slow.a_a[pos] = p.a;
+                            lds.slow.a_n[pos] = p.n; lds.slow.a_r[pos] = p.r; lds.slow.a_term[pos] = p.term ? 1 : 0;
+                            lds.pending[i] = 0;
+                        }
+                        barrier_lds();
+                        if (tid < CAP / 32) lds.def_bits[tid] = 0u;
+                        slow_body<T, Env, CAP, PERSIST_CACHE_BYTES, 0>(
+                            cc, ev, FLAG_NO_STAMPS | FLAG_LEARN | FLAG_PRESTAGED, t, n_def, lds.slow);
+                    } else {
+                        if (mine_def) {
+                            cc.s[i] = p.s; cc.a[i] = p.a; cc.pred[i] = p.pred; cc.r[i] = p.r;
+                            cc.term[i] = p.term ? 1 : 0; cc.n[i] = p.n; cc.aux[i] = p.aux;
+                            atomicOr(&cc.inv_bitmap[i >> 5], 1u << (i & 31));
+                            lds.pending[i] = 0;
+                        }
+                        __syncthreads();
+                        (void)build_involved_list(cc, lds.slow.scan);  // == n_def agents
+                        slow_body<T, Env, CAP, PERSIST_CACHE_BYTES, 0>(cc, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
+                    }
+                    __syncthreads();
+                } else {
+                    // every contested row has two touchers: the second one follows the first, in place.
+                    // lds.n_def itself counts down (every wave has copied it into `n_def` above)
+                    bool mine = active && !(cls & 1);
+                    int rounds = 0;
+                    while (lds.n_def > 0u && rounds++ <= n_def) {
+#ifdef QE_STAMPS
+                        if (tid == 0) c.vinc[18] += 1.0;
+#endif
+                        const bool go = mine && (pred_s < 0 || lds.pending[pred_s] == 0) &&
+                                        (pred_n < 0 || lds.pending[pred_n] == 0);
+                        barrier_lds();  // everyone has sampled the flags of this round
+                        if (go) {
+                            T m = 0;
+                            if (!p.term) {
+                                RowV<T, NV> fresh;
+                                load_row_lane<NV>(fresh, c.q, p.n);
+                                m = row_max_lane(masked_row<MASKED>(fresh, valid));
+                            }
+                            const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
+                            const T q0 = c.q[cell];
+                            T u;
+                            c.q[cell] = Td<T>::apply(q0, p.r, m, p.term, make_hyper(c, c.lr[t]), 0, &u);
+                            log_delta(c, t, i, cell, u);
+                            lds.pending[i] = 0;
+                            atomicSub(&lds.n_def, 1u);
+                            mine = false;
+                        }
+                        __syncthreads();  // this round's table writes are complete and visible
+                    }
+                    if (tid == 0 && lds.n_def > 0u) reinterpret_cast<const Ctx<T>*>(lds.cold)->ctrl->error = 2u;
+                }
+            }
+            // every update of step t is in the table: late selections read their row again
+            if (active && cls != 3 && !last) {
+                RowV<T, NV> fresh;
+                load_row_lane<NV>(fresh, c.q, p.n);
+                advance(fresh, valid, t + 1, x);
+            }
+            if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }
+#ifdef QE_STAMPS
+            if (tid == 0) c.vinc[19] += (double)(wall_clock64() - ext_t0);
+#endif
+        }
+        // ---- bulk flush of the staged episode log (uniform, data-independent decision) ----------
+        if (--flush_in == 0 || last) {
+            flush_in = flush_every;
+            __syncthreads();
+            const unsigned staged = lds.ep_n;
+            const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+            unsigned long long* const out_key = cc.ep_key;
+            float* const out_ret = cc.ep_ret;
+            const long long out_cap = cc.ep_cap;
+            for (unsigned k = tid; k < min(staged, (unsigned)EP_STAGE); k += blockDim.x) {
+                const unsigned long long pos = ep_base + k;
+                if ((long long)pos < out_cap) { out_key[pos] = lds.ep_key[k]; out_ret[pos] = lds.ep_ret[k]; }
+            }
+            ep_base += staged;
+            __syncthreads();
+            if (tid == 0) lds.ep_n = 0u;
+        }
+        tb = tb == 2 ? 0 : tb + 1;
+        if (c.dlog) dl += c.N;
+        QL_STAMP(6);
+    }
+#ifdef QE_STAMPS
+    if (tid == 0 && c.vinc) for (int k = 0; k < 8; ++k) c.vinc[k] = (double)stamp_sum[k];
+#endif
+    const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+    if (active) {
+        cc.n[i] = p.n; cc.aux[i] = p.aux; cc.acc[i] = acc;
+        if (cc.hb) { cc.hb_obs[i] = p.n; cc.hb_aux[i] = p.aux; cc.hb_acc[i] = acc; }
+    }
+    if (tid == 0) {
+        cc.ctrl->involved_total = deferred_total;
+        cc.ctrl->ep_count = ep_base;
+        cc.ctrl->t_local = steps;
+    }
+    if (cc.hb) {
+        // publish to the host: every wave's stores to the pinned arrays have left the GPU (vmcnt), then
+        // one lane writes the block and, last, the sequence number the host is spinning on
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            HostBlock* hb = cc.hb;
+            hb->ep_count = ep_base;
+            hb->involved_total = deferred_total;
+            hb->error = cc.ctrl->error;
+            hb->clk0 = clk0;
+            hb->clk1 = wall_clock64();
+            __threadfence_system();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&hb->seq, cc.hb_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+}  // namespace qe

@@ -232,8 +232,8 @@ def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="a
     Algo, Runtime, _, _ = _product()
     env = make_device_env(spec)
     algo = Algo(env.state_size, env.action_size, gamma, seed=seed, dtype=np.dtype(dt))
-    if path == "persistent" and (env.num_agents * algo.lanes_per_row > 1024 or env.num_agents > 512):
-        pytest.skip("more than 512 agents / 1024 lanes: the persistent kernel does not apply")
+    if path == "persistent" and (env.action_size > 64 or env.num_agents > 512):
+        pytest.skip("more than 512 agents / 64 actions: the persistent kernel does not apply")
     if path == "wide_listed":  # the compacted-list rounds (automatic from 16384 agents), seven rounds
         from dist_classicrl_amd import _lib
         algo.set_rollout_path("wide")
