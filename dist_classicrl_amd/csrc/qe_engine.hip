@@ -576,6 +576,10 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     if (sl.timed) HIP_TRY(hipEventRecord(sl.ev0, e->stream));
     if (persistent) {
         const unsigned block = (unsigned)((env->N + 63) / 64 * 64);
+#ifdef QE_EXPERIMENT
+        const int FLAG_ACCOUNT_X = FLAG_ACCOUNT | (getenv("QE_DEBUG_FLAGS") ? atoi(getenv("QE_DEBUG_FLAGS")) << 20 : 0);
+#define FLAG_ACCOUNT FLAG_ACCOUNT_X
+#endif
         const bool lean = mode == QE_LEARN_ITER && !c.trace;
         auto go = [&](auto nv, auto masked) {
             constexpr int NV = decltype(nv)::value;
@@ -585,14 +589,18 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             constexpr bool HAS_LEAN = std::is_same<T, float>::value &&
                                       ((std::is_same<Env, HashEnv>::value && !MK && (NV == 2 || NV == 4)) ||
                                        std::is_same<Env, TttEnv>::value);
-            if (HAS_LEAN && lean && block <= 128 && !c.dlog)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0>), dim3(1), dim3(block), 0, e->stream,
-                                   sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+            const bool full = (int64_t)block == env->N;  // every lane of the agents' wavefronts holds an agent
+            if (HAS_LEAN && lean && block <= 128 && !c.dlog && full)  // (+ one draw-producing wavefront per wavefront of agents)
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(2 * block), 0,
+                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+            else if (HAS_LEAN && lean && block <= 128 && !c.dlog)
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, false>), dim3(1), dim3(2 * block), 0,
+                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if (HAS_LEAN && lean && block <= 128)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0>), dim3(1), dim3(block), 0, e->stream,
-                                   sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, false>), dim3(1), dim3(2 * block), 0,
+                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, LANE_MAX_AGENTS, MK, 0>), dim3(1), dim3(block), 0, e->stream,
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, LANE_MAX_AGENTS, MK, 0, false, false>), dim3(1), dim3(block), 0, e->stream,
                                    sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
         };
         using Yes = std::true_type;
@@ -612,6 +620,9 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             go(std::integral_constant<int, 1>{}, No{});  // GridLake (A = 4) and the bandit (A = 2)
         }
         ++sl.launches;
+#ifdef QE_EXPERIMENT
+#undef FLAG_ACCOUNT
+#endif
     } else if (learn) {
         const int base = FLAG_ACCOUNT;
         launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_SELECT, false);  // select(0), env.step(0)
@@ -706,6 +717,10 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         if (int rc = wait_host_block(e, sl)) return rc;
         fin.ep_count = sl.hb->ep_count; fin.involved_total = sl.hb->involved_total; fin.error = sl.hb->error;
         clock_ms = (double)(sl.hb->clk1 - sl.hb->clk0) / e->wall_clock_khz;
+        if (getenv("QE_PRINT_CLOCK") && sl.hb->clk1 > sl.hb->clk0)
+            fprintf(stderr, "  [clock] %.0f MHz shader clock over %.1f us (%lld steps)\n",
+                    (double)(sl.hb->cyc1 - sl.hb->cyc0) / ((double)(sl.hb->clk1 - sl.hb->clk0) / e->wall_clock_khz * 1e3),
+                    clock_ms * 1e3, (long long)sl.steps);
         if (sl.timed) HIP_TRY(hipEventSynchronize(sl.ev1));
         // the environment's state after this rollout sits in the block (unless the next rollout of a
         // pipelined call is already moving it on)

@@ -74,6 +74,7 @@ struct HostBlock {
     unsigned long long ep_count;        // episode-log entries written
     unsigned long long involved_total;  // agents that reached the ordered path
     unsigned long long clk0, clk1;      // s_memrealtime (100 MHz) at the start / end of the launch
+    unsigned long long cyc0, cyc1;      // s_memtime (shader clock) at the same two points
     unsigned int error, pad;
 };
 

@@ -26,7 +26,6 @@
 namespace qe {
 
 constexpr int LANE_MAX_AGENTS = 512;
-constexpr int LANE_CT_SLOTS = 2048;  // >= 2 x touches per step (two per agent)
 
 template <typename T, int NV>
 struct RowV {
@@ -173,57 +172,80 @@ __device__ __forceinline__ typename LaneMask<NV>::type valid_mask_lane(const Env
     }
 }
 
+// HELP: the launch carries one extra wavefront per wavefront of agents whose only job is to evaluate the
+// Philox blocks of the coming steps into an LDS ring (the draws depend on nothing but (agent, step)), on
+// SIMDs the agents' wavefronts leave idle: ~100 vector instructions per step off the critical path.
+//
+// Contention tracking.  A row is contested in a step when it is WRITTEN in that step and touched by a
+// second agent.  Four rotating LDS hash sets `wt[k & 3]` hold the rows written in step k; the row an
+// agent writes in step k+1 is its observation after step k-1, so it is inserted two steps ahead:
+//   end of iteration t (transition t+1 = (s, a, n) just selected), ONE LDS round trip:
+//     insert   n into wt[t+2]   (n is the row written in step t+2); found there already => step t+2 busy (W-W)
+//     look up  n in  wt[t+1]    (rows written in step t+1, complete since the last barrier); found => step t+1 busy (W-R)
+//     look up  n in  wt[t]      (rows written in step t, possibly still in flight): found => the row gathered
+//                               before the barrier may be stale: gather it again behind the barrier
+//     retire   my entry of wt[t-1]
+// Quiet steps need nothing else.  A busy step registers all touches exactly (row -> writers, readers,
+// lowest toucher) in a separate table, from scratch, and classifies from that.
 template <int CAP>
+struct LaneCfg {
+    static constexpr int WT = CAP <= 128 ? 4096 : 2048;  // slots of a written-rows set (<= CAP entries each)
+    static constexpr int BT = 2048;                      // slots of the busy-step table (<= 2 * CAP entries)
+};
+
+template <int CAP, bool HELP>
 struct LaneLds {
     SlowLdsT<CAP, PERSIST_CACHE_BYTES> slow;
-    unsigned long long ct[3][LANE_CT_SLOTS];  // (row + 1) << 32 | writers << 16 | readers; 0 = free
-    int ct_min[3][LANE_CT_SLOTS];             // lowest toucher index
+    int wt[4][LaneCfg<CAP>::WT + 1];     // rows written in step k (mod 4), -1 = free; last = dump slot
+    int bt_key[LaneCfg<CAP>::BT];        // busy step: row
+    unsigned bt_cnt[LaneCfg<CAP>::BT];   //            writers << 16 | readers
+    int bt_min[LaneCfg<CAP>::BT];        //            lowest toucher index
+    uint32_t draws[2][3][HELP ? CAP : 1];  // ring of Philox words x0, x1, x2 per agent (step parity)
     unsigned long long ep_key[EP_STAGE];
     float ep_ret[EP_STAGE];
     unsigned char pending[CAP];   // 1 while an agent's deferred update is outstanding
     alignas(16) unsigned char cold[384];  // the launch context, for the rare paths
     unsigned def_bits[CAP / 32];  // deferred agents of a step (general ordered path), by index
-    unsigned busy[3];             // step t: some row has more than one toucher
+    unsigned busy[5];             // step k (mod 4): some written row has a second toucher; [4] = dump
     unsigned ep_n;
     unsigned n_def;       // agents whose update is deferred in this step
     unsigned complex_;    // a contested row has more than two touchers
 };
 
-// Registers a touch of `row` in table `tb`: one 64-bit compare-and-swap when this agent is the row's
-// first toucher of the step; a second toucher adds its count (and raises the step's busy flag).
-template <int CAP>
-__device__ __forceinline__ int lane_touch(LaneLds<CAP>& l, int tb, int32_t row, unsigned kind, int agent) {
-    const unsigned long long key = (unsigned long long)((uint32_t)row + 1u) << 32;
-    int h = (int)(mix32((uint32_t)row) & (LANE_CT_SLOTS - 1));
-    for (;;) {
-        const unsigned long long old = atomicCAS(&l.ct[tb][h], 0ull, key | kind);
-        if (old == 0ull) break;
-        if ((old >> 32) == (key >> 32)) {
-            atomicAdd(&l.ct[tb][h], (unsigned long long)kind);
-            l.busy[tb] = 1u;
-            break;
-        }
-        h = (h + 1) & (LANE_CT_SLOTS - 1);
-    }
-    atomicMin(&l.ct_min[tb][h], agent);
-    return h;
-}
-
+#ifdef QE_EXPERIMENT
+#define QX(bit) ((flags >> (20 + (bit))) & 1)
+#else
+#define QX(bit) 0
+#endif
 #ifdef QE_STAMPS
 #define QL_STAMP(k) do { const long long _n = wall_clock64(); stamp_sum[k] += _n - stamp_last; stamp_last = _n; } while (0)
 #else
 #define QL_STAMP(k) do { } while (0)
 #endif
 
+// Step barrier of the rollout loop: this wave's table stores are complete (they were issued before the
+// `PENDING_LOADS` youngest vector-memory operations, the early row gather of the next step, which stays
+// in flight across the barrier), LDS traffic is complete, all waves have arrived.
+template <int PENDING_LOADS>
+__device__ __forceinline__ void step_barrier() {
+    if constexpr (PENDING_LOADS == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PENDING_LOADS) : "memory");
+}
+
 // LEAN: 1 = plain training rollout (sequential learn, no action trace, no delta log), 2 = the same with
 // the delta log of the replica exchange; known at compile time, which drops their uniform branches
 // and operands from the loop.
-template <typename T, class Env, int NV, int CAP, bool MASKED, int LEAN = 0>
-__global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 of the kernarg segment*/,
-                                                      Ctx<T> c, EnvCtx ev, long long steps, int flags) {
+// FULL: every lane of the agents' wavefronts holds an agent (N is a multiple of 64), so "this lane is
+// active" is a per-wavefront fact and the per-agent sections need no exec-mask bookkeeping.
+template <typename T, class Env, int NV, int CAP, bool MASKED, int LEAN = 0, bool HELP = false, bool FULL = false>
+__global__ __launch_bounds__(HELP ? 2 * CAP : CAP) void k_rollout_lane(InlineSched /*at offset 0 of the kernarg segment*/,
+                                                                       Ctx<T> c, EnvCtx ev, long long steps, int flags) {
     using M = typename LaneMask<NV>::type;
-    __shared__ LaneLds<CAP> lds;
+    constexpr int NLOAD = NV * (int)(sizeof(T) / 4);  // 16-byte loads of one row gather
+    constexpr int WT = LaneCfg<CAP>::WT, BT = LaneCfg<CAP>::BT;
+    __shared__ LaneLds<CAP, HELP> lds;
     const unsigned long long clk0 = wall_clock64();
+    const unsigned long long cyc0 = __builtin_amdgcn_s_memtime();
     if (c.thr == nullptr) {  // short rollout: the schedule values came with the launch
         const QE_AS4 unsigned char* ka = (const QE_AS4 unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
         c.thr = (const QE_AS4 unsigned long long*)ka;
@@ -237,22 +259,24 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
     if (threadIdx.x == 0) for (int k = 8; k < 24; ++k) c.vinc[k] = 0.0;
 #endif
     const int tid = threadIdx.x;
-    const int i = tid;
-    const bool active = i < c.N;
-    const int ii = active ? i : 0;
+    // agents' wavefronts first, then (HELP) as many draw-producing wavefronts
+    const int n_main = HELP ? (int)(blockDim.x >> 1) : (int)blockDim.x;
+    const bool helper = HELP && __builtin_amdgcn_readfirstlane(tid) >= n_main;  // (uniform per wavefront)
+    const int i = helper ? tid - n_main : tid;
+    const bool active = FULL ? !helper : (!helper && i < c.N);
+    const int ii = i < c.N ? i : 0;
     Pending<T> p;
     p.n = c.n[ii];
     p.aux = c.aux[ii];
     p.s = 0; p.a = 0; p.pred = 0; p.r = 0.0f; p.term = false;
     float acc = c.acc[ii];
     unsigned long long deferred_total = 0, ep_base = 0;
-    int cur_s = -1, cur_n = -1, prev_s = -1, prev_n = -1;  // my slots of steps t-1 / t-2
+    // my entries of the written-rows sets of steps t+1, t, t-1 (dump slot: none)
+    int w_next = WT, w_cur = WT, w_prev = WT;
     const int flush_every = 32;  // steps per flush window of the staged episode log
     int flush_in = flush_every;
-    for (int k = tid; k < 3 * LANE_CT_SLOTS; k += (int)blockDim.x) {
-        (&lds.ct[0][0])[k] = 0ull;
-        (&lds.ct_min[0][0])[k] = 0x7FFFFFFF;
-    }
+    for (int k = tid; k < 4 * (WT + 1); k += (int)blockDim.x) (&lds.wt[0][0])[k] = -1;
+    for (int k = tid; k < BT; k += (int)blockDim.x) { lds.bt_key[k] = -1; lds.bt_cnt[k] = 0u; lds.bt_min[k] = 0x7FFFFFFF; }
     for (int k = tid; k < CAP; k += (int)blockDim.x) lds.pending[k] = 0;
     if (tid < CAP / 32) lds.def_bits[tid] = 0u;
     // what only the rare paths need (agent arrays for the general ordered path, log pointers for the
@@ -261,15 +285,15 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
     if (tid == 0) {
         *reinterpret_cast<Ctx<T>*>(lds.cold) = c;
         lds.ep_n = 0u; lds.n_def = 0u; lds.complex_ = 0u;
-        lds.busy[0] = lds.busy[1] = lds.busy[2] = 0u;
+        for (int k = 0; k < 5; ++k) lds.busy[k] = 0u;
         c.ctrl->error = 0u;  // this launch owns the control block: no host-side memset in front of it
         c.ctrl->inv_count = 0u;
     }
-    __syncthreads();  // the control block is initialised before any wave may report through it
+    __syncthreads();  // tables and control block are initialised
 
     // selection + env.step of step t1 from `row` (= Q[p.n]); the new pending transition replaces p
-    auto advance = [&](const RowV<T, NV>& row, M valid, long long t1, const U4& x) {
-        const bool explore = (unsigned long long)x.x < c.thr[t1];
+    auto advance = [&](const RowV<T, NV>& row, M valid, long long t1, const U4& x, unsigned long long thr_t1) {
+        const bool explore = (unsigned long long)x.x < thr_t1;
         T picked;
         int act = select_lane<T, NV, M>(masked_row<MASKED>(row, valid), valid, explore, x.y, x.z, &picked);
         if (act < 0) {
@@ -284,93 +308,171 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
         if (c.trace) c.trace[t1 * c.N + i] = act;
         p.s = n; p.a = act; p.pred = picked; p.r = tr.reward; p.term = tr.terminated; p.n = tr.next_obs;
     };
-    auto draws = [&](long long t1) {
+    auto philox_of = [&](long long t1) {
         const unsigned long long step1 = c.step0 + (unsigned long long)t1;
         return philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)step1, (uint32_t)(step1 >> 32), STREAM_POLICY,
                              c.seed_lo, c.seed_hi);
     };
+    // draws of step t1: from the helpers' ring (published by the barrier in front of this iteration)
+    auto draws = [&](long long t1) {
+        if constexpr (HELP) {
+            const int slot = (int)(t1 & 1);
+            return U4{lds.draws[slot][0][ii], lds.draws[slot][1][ii], lds.draws[slot][2][ii], 0u};
+        } else {
+            return philox_of(t1);
+        }
+    };
+    auto produce = [&](long long t1) {  // helper wavefronts: the block of step t1 into its ring slot
+        const U4 x = philox_of(t1);
+        const int slot = (int)(t1 & 1);
+        lds.draws[slot][0][ii] = x.x; lds.draws[slot][1][ii] = x.y; lds.draws[slot][2][ii] = x.z;
+    };
+    // The contention bookkeeping of the transition pending in p (step k): see the top of this section.
+    // Returns whether the gathered row of p.n may be stale.  The three operations share the hash of p.n and
+    // travel together: ONE LDS round trip, plus one more per round of linear probing past slots held by
+    // other rows (some lane of a wavefront needs one in most steps, so the three probe sequences advance
+    // side by side, straight-line: a lane that is done aims at the dump slot).
+    auto bookkeeping = [&](long long k, bool check_stale) {
+        int* const tab_w = lds.wt[(k + 1) & 3];
+        const int* const tab_r = lds.wt[k & 3];
+        const int* const tab_st = lds.wt[(k + 3) & 3];  // step k-1
+        const int32_t rowid = p.n;
+        const int h = (int)(mix32((uint32_t)rowid) & (WT - 1));
+        const bool need_r = rowid != p.s;
+        int o_w = atomicCAS(&tab_w[h], -1, rowid);
+        int k_r = need_r ? tab_r[h] : -1;
+        int k_st = check_stale ? tab_st[h] : -1;
+        int h_w = h, h_r = h, h_st = h;
+        bool odd_w = o_w != -1 && o_w != rowid, odd_r = k_r != -1 && k_r != rowid, odd_st = k_st != -1 && k_st != rowid;
+        while (__any(odd_w || odd_r || odd_st)) {
+            h_w = odd_w ? (h_w + 1) & (WT - 1) : h_w;
+            h_r = (h_r + 1) & (WT - 1);
+            h_st = (h_st + 1) & (WT - 1);
+            const int o2 = atomicCAS(&tab_w[odd_w ? h_w : WT], odd_w ? -1 : -2, rowid);
+            const int r2 = tab_r[odd_r ? h_r : WT];
+            const int s2 = tab_st[odd_st ? h_st : WT];
+            o_w = odd_w ? o2 : o_w; k_r = odd_r ? r2 : k_r; k_st = odd_st ? s2 : k_st;
+            odd_w = o_w != -1 && o_w != rowid; odd_r = k_r != -1 && k_r != rowid; odd_st = k_st != -1 && k_st != rowid;
+        }
+        lds.busy[o_w == rowid ? (int)((k + 1) & 3) : 4] = 1u;  // written by two agents in step k+1
+        lds.busy[k_r == rowid ? (int)(k & 3) : 4] = 1u;        // read here, written by another agent in step k
+        w_prev = w_cur; w_cur = w_next; w_next = h_w;
+        return k_st == rowid;
+    };
 
-    {   // select(0), env.step(0)
-        RowV<T, NV> row;
+    RowV<T, NV> row;   // Q[p.n] of the step about to be processed: gathered before its barrier
+    bool stale = false;  // ... unless someone wrote that row in the step before: gathered again after it
+    {   // select(0), env.step(0); rows written in step 0; then the bookkeeping of transition 0
         load_row_lane<NV>(row, c.q, p.n);
-        if (active) advance(row, valid_mask_lane<Env, NV, MASKED>(ev, i, p.n), 0, draws(0));
+        if (active) {
+            advance(row, valid_mask_lane<Env, NV, MASKED>(ev, i, p.n), 0, philox_of(0), c.thr[0]);
+            int h = (int)(mix32((uint32_t)p.s) & (WT - 1));
+            int old = atomicCAS(&lds.wt[0][h], -1, p.s);
+            while (old != -1 && old != p.s) {
+                h = (h + 1) & (WT - 1);
+                old = atomicCAS(&lds.wt[0][h], -1, p.s);
+            }
+            if (old == p.s) lds.busy[0] = 1u;
+            w_next = h;
+        }
+        if (helper) produce(1);
+        __syncthreads();
+        if (active) (void)bookkeeping(0, false);
+        load_row_lane<NV>(row, c.q, p.n);
     }
     __syncthreads();
-    int tb = 0;  // t % 3
     DeltaEntry* dl = c.dlog ? c.dlog + c.dlog_base + ii : nullptr;  // this agent's record of step 0
     const long long dl_steps = c.dlog ? (c.dlog_cap - c.dlog_base) / c.N : 0;  // steps whose records all fit
+    // schedule values are fetched one step ahead of their use (scalar loads whose latency would otherwise
+    // sit in front of the update / the selection of every step)
+    double lr_t = c.lr[0];
+    unsigned long long thr_t1 = c.thr[steps > 1 ? 1 : 0];
     for (long long t = 0; t < steps; ++t) {
         const bool last = t + 1 == steps;
         const bool dl_ok = t < dl_steps;
-        const int tb_old = tb == 2 ? 0 : tb + 1;  // (t - 2) % 3 == (t + 1) % 3: retired two barriers ago
+        const double lr_next = c.lr[last ? t : t + 1];
+        const unsigned long long thr_next = c.thr[t + 2 < steps ? t + 2 : steps - 1];
         QL_STAMP(7);
-        // ---- register this step's touches (W(s), R(n)); retire my entries of step t-2 -----------
-        if (active) {
-            if (prev_s >= 0) { lds.ct[tb_old][prev_s] = 0ull; lds.ct_min[tb_old][prev_s] = 0x7FFFFFFF; }
-            if (prev_n >= 0) { lds.ct[tb_old][prev_n] = 0ull; lds.ct_min[tb_old][prev_n] = 0x7FFFFFFF; }
-            prev_s = cur_s; prev_n = cur_n;
-            cur_s = lane_touch(lds, tb, p.s, 1u << 16, i);
-            cur_n = p.n != p.s ? lane_touch(lds, tb, p.n, 1u, i) : -1;
-        }
-        if (tid == 0) lds.busy[tb_old] = 0u;
-        QL_STAMP(0);
-        __syncthreads();  // every table write of step t-1 is complete; touches of step t are in
-        QL_STAMP(1);
-        const bool busy = lds.busy[tb] != 0u;
-        RowV<T, NV> row;
-        load_row_lane<NV>(row, c.q, p.n);  // the one row gather of a quiet step
+        const bool busy = lds.busy[t & 3] != 0u;
+        const U4 x = draws(t + 1);
+        if (helper && !last) produce(t + 2);
+        if (stale) load_row_lane<NV>(row, c.q, p.n);
         const M valid = valid_mask_lane<Env, NV, MASKED>(ev, ii, p.n);
-        // ---- classification (only when some row has several touchers) ---------------------------
+        QL_STAMP(0);
+        // ---- busy step: exact registration of every touch, then classification ---------------------
         int cls = 3;  // bit0: update now, bit1: select now
         int pred_s = -1, pred_n = -1;
-        if (busy && active) {
-            const unsigned long long ws = lds.ct[tb][cur_s];
-            const unsigned cs = (unsigned)ws;
-            const int ms = lds.ct_min[tb][cur_s];
-            unsigned cn = 0u;
-            int mn = 0x7FFFFFFF;
-            const bool has_n = cur_n >= 0;
-            if (has_n) { cn = (unsigned)lds.ct[tb][cur_n]; mn = lds.ct_min[tb][cur_n]; }
-            const unsigned w_s = cs >> 16, tot_s = w_s + (cs & 0xFFFFu);
-            const unsigned w_n = cn >> 16, tot_n = w_n + (cn & 0xFFFFu);
-            bool now = true, sel = true, cx = false;
-            if (c.mode == 1) {
-                // VEC (learn_vec): every toucher of a row that is written AND shared reads the
-                // pre-step table, so all of them go through the batch path together
-                const bool shared = w_s >= 2u || (w_s == 1u && tot_s >= 2u) || (has_n && w_n >= 1u && tot_n >= 2u);
-                if (shared) { now = false; cx = true; }
-                sel = !(has_n ? w_n > 0u : w_s > 1u);
-            } else {
-                if (tot_s > 1u && ms < i) { now = false; pred_s = ms; cx |= tot_s > 2u; }
-                if (has_n) {
-                    if (w_n > 0u) {
-                        sel = false;  // someone writes the row my next action is chosen from
-                        if (!p.term && mn < i) { now = false; pred_n = mn; cx |= tot_n > 2u; }
+        int b_s = -1, b_n = -1;
+        if (busy) {
+            if (active) {
+                auto bt_insert = [&](int32_t rowid) {
+                    int h = (int)(mix32((uint32_t)rowid) & (BT - 1));
+                    for (;;) {
+                        const int old = atomicCAS(&lds.bt_key[h], -1, rowid);
+                        if (old == -1 || old == rowid) return h;
+                        h = (h + 1) & (BT - 1);
                     }
-                } else if (w_s > 1u) {
-                    sel = false;  // n == s and another agent writes this row too
+                };
+                b_s = bt_insert(p.s);
+                atomicAdd(&lds.bt_cnt[b_s], 1u << 16);
+                atomicMin(&lds.bt_min[b_s], i);
+                if (p.n != p.s) {
+                    b_n = bt_insert(p.n);
+                    atomicAdd(&lds.bt_cnt[b_n], 1u);
+                    atomicMin(&lds.bt_min[b_n], i);
                 }
             }
-            cls = (now ? 1 : 0) | (sel ? 2 : 0);
-            if (!now) {
-                lds.pending[i] = 1;
-                atomicAdd(&lds.n_def, 1u);
-                if (cx) lds.complex_ = 1u;
+            barrier_lds();
+            if (active) {
+                const unsigned cs = lds.bt_cnt[b_s];
+                const int ms = lds.bt_min[b_s];
+                unsigned cn = 0u;
+                int mn = 0x7FFFFFFF;
+                const bool has_n = b_n >= 0;
+                if (has_n) { cn = lds.bt_cnt[b_n]; mn = lds.bt_min[b_n]; }
+                const unsigned w_s = cs >> 16, tot_s = w_s + (cs & 0xFFFFu);
+                const unsigned w_n = cn >> 16, tot_n = w_n + (cn & 0xFFFFu);
+                bool now = true, sel = true, cx = false;
+                if (c.mode == 1) {
+                    // VEC (learn_vec): every toucher of a row that is written AND shared reads the
+                    // pre-step table, so all of them go through the batch path together
+                    const bool shared = w_s >= 2u || (w_s == 1u && tot_s >= 2u) || (has_n && w_n >= 1u && tot_n >= 2u);
+                    if (shared) { now = false; cx = true; }
+                    sel = !(has_n ? w_n > 0u : w_s > 1u);
+                } else {
+                    if (tot_s > 1u && ms < i) { now = false; pred_s = ms; cx |= tot_s > 2u; }
+                    if (has_n) {
+                        if (w_n > 0u) {
+                            sel = false;  // someone writes the row my next action is chosen from
+                            if (!p.term && mn < i) { now = false; pred_n = mn; cx |= tot_n > 2u; }
+                        }
+                    } else if (w_s > 1u) {
+                        sel = false;  // n == s and another agent writes this row too
+                    }
+                }
+                cls = (now ? 1 : 0) | (sel ? 2 : 0);
+                if (!now) {
+                    lds.pending[i] = 1;
+                    atomicAdd(&lds.n_def, 1u);
+                    if (cx) lds.complex_ = 1u;
+                }
             }
         }
         QL_STAMP(2);
-        // ---- Philox draws of select(t+1): independent of memory, computed under the row gather ----
-        const U4 x = draws(t + 1);
+        // The row gather (issued before the barrier, or just above) has landed: an explicit wait that the
+        // compiler's counter tracking understands.  Without it every path on which `row` is not read
+        // leaves the loads "pending" in its analysis, and it drains vector memory -- this step's table
+        // store included -- in front of the NEXT gather.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         const float r_t = p.r;
         const bool term_t = p.term;
-        QL_STAMP(3);
         // ---- update of transition t for agents that may go now ----------------------------------
         if (active && (cls & 1)) {
             const T m = row_max_lane(masked_row<MASKED>(row, valid));
             const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
             T u;
-            const T q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, c.lr[t]), c.mode, &u);
-            c.q[cell] = q1;
+            const T q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), c.mode, &u);
+            if (!QX(1)) c.q[cell] = q1;
             // delta log of the replica exchange: a running pointer (slot = base + t * N + agent)
             if (dl_ok) *dl = DeltaEntry{(uint32_t)cell, (float)u};
             if (p.n == p.s) {  // own write lands in the row held in registers
@@ -402,7 +504,7 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
             }
         }
         QL_STAMP(4);
-        if (active && cls == 3 && !last) advance(row, valid, t + 1, x);
+        if (active && cls == 3 && !last) advance(row, valid, t + 1, x, thr_t1);
         QL_STAMP(5);
 
         if (busy) {
@@ -412,6 +514,10 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
 #endif
             __syncthreads();
             const int n_def = (int)lds.n_def;
+            if (active) {  // the step's registration has been read by everyone: take it down again
+                lds.bt_key[b_s] = -1; lds.bt_cnt[b_s] = 0u; lds.bt_min[b_s] = 0x7FFFFFFF;
+                if (b_n >= 0) { lds.bt_key[b_n] = -1; lds.bt_cnt[b_n] = 0u; lds.bt_min[b_n] = 0x7FFFFFFF; }
+            }
 #ifdef QE_STAMPS
             if (tid == 0) { c.vinc[16] += 1.0; if (n_def > 0) c.vinc[17] += 1.0; }
 #endif
@@ -479,7 +585,7 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
                             const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
                             const T q0 = c.q[cell];
                             T u;
-                            c.q[cell] = Td<T>::apply(q0, p.r, m, p.term, make_hyper(c, c.lr[t]), 0, &u);
+                            c.q[cell] = Td<T>::apply(q0, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
                             log_delta(c, t, i, cell, u);
                             lds.pending[i] = 0;
                             atomicSub(&lds.n_def, 1u);
@@ -494,9 +600,10 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
             if (active && cls != 3 && !last) {
                 RowV<T, NV> fresh;
                 load_row_lane<NV>(fresh, c.q, p.n);
-                advance(fresh, valid, t + 1, x);
+                advance(fresh, valid, t + 1, x, thr_t1);
             }
             if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // (busy step: nothing in flight on any path, see above)
 #ifdef QE_STAMPS
             if (tid == 0) c.vinc[19] += (double)(wall_clock64() - ext_t0);
 #endif
@@ -518,9 +625,20 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
             __syncthreads();
             if (tid == 0) lds.ep_n = 0u;
         }
-        tb = tb == 2 ? 0 : tb + 1;
-        if (c.dlog) dl += c.N;
         QL_STAMP(6);
+        if (last) break;
+        // ---- transition t+1 is pending in p: gather its row; under the gather, one LDS round trip of
+        // contention bookkeeping (top of this section); retire my entry of the set of step t-1 ---------
+        lds.wt[(t + 3) & 3][w_prev] = -1;     // (t-1 mod 4; lanes without an entry write the dump slot)
+        if (tid == 0) lds.busy[(t + 3) & 3] = 0u;  // flag of step t-1: every wave has read it since
+        asm volatile("" ::: "memory");  // the gather stays behind every store of this step (vmcnt counts in order)
+        if (!helper && !QX(0)) load_row_lane<NV>(row, c.q, p.n);
+        asm volatile("" ::: "memory");
+        if (active && !QX(2)) stale = bookkeeping(t + 1, true);
+        QL_STAMP(1);
+        if (!QX(4)) step_barrier<NLOAD>();  // table writes of step t are complete; the sets of steps t+1, t+2 are in
+        lr_t = lr_next; thr_t1 = thr_next;
+        if (c.dlog) dl += c.N;
     }
 #ifdef QE_STAMPS
     if (tid == 0 && c.vinc) for (int k = 0; k < 8; ++k) c.vinc[k] = (double)stamp_sum[k];
@@ -547,6 +665,8 @@ __global__ __launch_bounds__(CAP) void k_rollout_lane(InlineSched /*at offset 0 
             hb->error = cc.ctrl->error;
             hb->clk0 = clk0;
             hb->clk1 = wall_clock64();
+            hb->cyc0 = cyc0;
+            hb->cyc1 = __builtin_amdgcn_s_memtime();
             __threadfence_system();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&hb->seq, cc.hb_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
