@@ -59,6 +59,8 @@ class RolloutStats(C.Structure):
         ("dominant_launches", C.c_int64),
         ("dominant_env_steps", C.c_int64),
         ("device_clock_ms", C.c_double),
+        ("host_begin_us", C.c_double),
+        ("host_end_us", C.c_double),
     ]
 
 
@@ -101,6 +103,8 @@ PROTOTYPES = {
     "qe_schedule_plan": (C.c_int, [_P, _F64P, _F64P, C.c_int64]),
     "qe_rollout_end": (C.c_int, [_P, C.c_int32, C.POINTER(RolloutStats)]),
     "qe_rollout_chunk_limit": (C.c_int64, [_P, _P, C.c_int32]),
+    "qe_rollout_fused": (C.c_int64, [_P, _P, C.c_int64, _F64P, _F64P, C.c_int32, C.POINTER(RolloutStats), C.c_int64, _I32P,
+                                     _F32P, _F32P, _I32P, _U32P, _F32P]),
     "qe_evaluate": (C.c_int, [_P, _P, C.c_int64, C.POINTER(RolloutStats)]),
     "qe_episode_log": (C.c_int64, [_P, C.c_int64, _I32P, _I32P, _F32P]),
     "qe_delta_log_attach": (C.c_int, [_P, _P, C.c_int64]),

@@ -28,10 +28,14 @@ def _schedule_values(schedule, n_updates, count):
     (short calls) or a float64 ndarray; the schedule is left advanced (base_runtime.py:248,262-263)."""
     if count <= _SHORT_CALL:
         out = (C.c_double * count)()
-        get, update = schedule.get_value, schedule.update
-        for t in range(count):
-            out[t] = get()
-            update(n_updates)
+        into = getattr(schedule, "advance_into", None)
+        if into is not None:
+            into(n_updates, count, out)
+        else:  # duck-typed schedule (e.g. the reference's classes)
+            get, update = schedule.get_value, schedule.update
+            for t in range(count):
+                out[t] = get()
+                update(n_updates)
         return out
     fast = getattr(schedule, "advance_values", None)
     if fast is not None:
@@ -76,6 +80,14 @@ class GpuRolloutQLearning(BaseRuntime):
         # element type, ~2x slower to build) or "array" (the float32 array itself: no per-episode
         # Python object; for runs that finish millions of episodes per call)
         self.history_type = "float"
+        # scratch of the one-call form of a short run_steps (qe_rollout_fused)
+        self._fused_cap = 4096
+        self._fused_step = np.empty(self._fused_cap, dtype=np.int32)
+        self._fused_ret = np.empty(self._fused_cap, dtype=np.float32)
+        self._fused_step_p = _lib.ptr(self._fused_step, C.c_int32)
+        self._fused_ret_p = _lib.ptr(self._fused_ret, C.c_float)
+        self._fused_sum = C.c_float()
+        self._fused_stats = _lib.RolloutStats()
 
     def _history(self, rets: np.ndarray):
         if self.history_type == "array":
@@ -120,7 +132,8 @@ class GpuRolloutQLearning(BaseRuntime):
         env._resident = None  # the device state moves on
         mode = _lib.LEARN_ITER if self.learn_mode == "iter" else _lib.LEARN_VEC
         total = {"kernel_ms": 0.0, "launches": 0, "episodes": 0, "involved": 0, "episodes_dropped": 0,
-                 "dominant_ms": 0.0, "dominant_launches": 0, "dominant_env_steps": 0, "device_clock_ms": 0.0}
+                 "dominant_ms": 0.0, "dominant_launches": 0, "dominant_env_steps": 0, "device_clock_ms": 0.0,
+                 "host_begin_us": 0.0, "host_end_us": 0.0}
         history, ep_steps, traces = [], [], []
         chunk_max = max(1, int(lib.qe_rollout_chunk_limit(algo.handle, env.handle, 1 if learn else 0)))
         sync = self.delta_sync if learn else None
@@ -218,6 +231,38 @@ class GpuRolloutQLearning(BaseRuntime):
         at = (ep_steps[0] if len(ep_steps) == 1 else np.concatenate(ep_steps)) if ep_steps else np.empty(0, dtype=np.int32)
         return rets, at
 
+    def _run_steps_fused(self, steps, env):
+        """``run_steps`` body as ONE engine call (``qe_rollout_fused``): schedule values in, episode returns,
+        their float32 sum and the resume state out.  For calls that fit one launch on an unmasked
+        environment without replica exchange or action trace -- in particular the short calls of a
+        step-by-step driver, whose cost is all per-call overhead."""
+        lib, algo, n = _lib.load(), self.algorithm, env.num_agents
+        env._resident = None  # the device state moves on
+        mode = _lib.LEARN_ITER if self.learn_mode == "iter" else _lib.LEARN_VEC
+        eps = _schedule_values(self.exploration_rate_schedule, n, steps)
+        lr = _schedule_values(self.lr_schedule, n, steps)
+        state = np.empty(3 * n, dtype=np.uint32)  # observations | env-internal state | running returns
+        base = state.ctypes.data
+        st = self._fused_stats
+        cnt = lib.qe_rollout_fused(algo.handle, env.handle, steps, _f64_ptr(eps), _f64_ptr(lr), mode, C.byref(st),
+                                   self._fused_cap, self._fused_step_p, self._fused_ret_p, C.byref(self._fused_sum),
+                                   C.cast(base, C.POINTER(C.c_int32)), C.cast(base + 4 * n, C.POINTER(C.c_uint32)),
+                                   C.cast(base + 8 * n, C.POINTER(C.c_float)))
+        if cnt < 0:
+            _lib.check(cnt)
+        if st.episodes_dropped:
+            msg = f"episode log overflow: {st.episodes_dropped} episode returns were dropped"
+            raise _lib.EngineError(msg)
+        if cnt <= self._fused_cap:
+            rets = self._fused_ret[:cnt].copy()
+        else:
+            rets = np.empty(cnt, dtype=np.float32)
+            lib.qe_episode_log(algo.handle, cnt, None, None, _lib.ptr(rets, C.c_float))
+        self.last_stats = {f: getattr(st, f) for f, _ in st._fields_}
+        obs, aux, rewards = state[:n].view(np.int32), state[n:2 * n], state[2 * n:].view(np.float32)
+        total = np.float32(self._fused_sum.value) if cnt else 0  # (0 / 0 -> ZeroDivisionError, like the reference)
+        return rets, total, env.adopt_state(obs, rewards, aux)
+
     def run_steps(self, steps, env, curr_state_dict=None):
         if not isinstance(env, DeviceVecEnv):
             return self._run_steps_host(steps, env, curr_state_dict)
@@ -229,9 +274,16 @@ class GpuRolloutQLearning(BaseRuntime):
             # dict this runtime returned last is recognised and costs nothing -- the environments never
             # left the GPU.
             env.restore(curr_state_dict["states"], curr_state_dict["rewards"], curr_state_dict.get("aux"))
-        rets, _ = self._rollout(env, steps, learn=True)
-        reward_history = self._history(rets)
-        state_dict = env.state_dict()
+        collect_trace = self.trace_actions is not None and self.trace_actions is not False
+        if (self.delta_sync is None and not collect_trace and not env.masked and 0 < steps <= env.chunk_limit(True)
+                and self.history_type == "float"):
+            rets, total, state_dict = self._run_steps_fused(steps, env)
+            reward_history = rets.tolist()
+        else:
+            rets, _ = self._rollout(env, steps, learn=True)
+            reward_history = self._history(rets)
+            total = _sequential_sum(rets)
+            state_dict = env.state_dict()
         state_dict["episode_rewards"] = reward_history
         # not part of the reference's dict (single_thread_runtime.py:70-75): what an exact resume in a
         # fresh process needs besides the table -- draw counter and schedule values (restore_training_state)
@@ -240,8 +292,8 @@ class GpuRolloutQLearning(BaseRuntime):
         state_dict["exploration_rate"] = self.exploration_rate_schedule.get_value()
         return (
             # sum(reward_history) / len(reward_history) of the reference (:67): a sequential float32
-            # accumulation, which is what cumsum computes; ZeroDivisionError if no episode ended
-            _sequential_sum(rets) / len(reward_history),
+            # accumulation (np.cumsum / the engine's running sum); ZeroDivisionError if no episode ended
+            total / len(reward_history),
             reward_history,
             env,
             state_dict,

@@ -212,6 +212,7 @@ struct qe_engine {
     int opt_timing = 1;  // QE_OPT_EVENT_TIMING: bracket rollouts with HIP events (persistent path: off = in-kernel clock only)
     int opt_host_block = 1;  // QE_OPT_HOST_BLOCK: persistent rollouts publish through the host result block
     unsigned long long seq_ctr = 0;
+    double host_begin_us = 0.0;  // diagnostics (QE_PRINT_HOST)
     hipStream_t stream = nullptr;
     bool own_stream = true;
     void* q = nullptr;
@@ -1389,9 +1390,18 @@ static int begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, co
                               : rollout_begin_dispatch<double>(e, env, sl, steps, mode, learn, trace);
 }
 
+static double now_us() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
 int qe_rollout_begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
                      int32_t mode, int32_t slot) {
-    return begin(e, env, steps, eps, lr, mode, 1, nullptr, slot);
+    const double t0 = now_us();
+    const int rc = begin(e, env, steps, eps, lr, mode, 1, nullptr, slot);
+    if (e) e->host_begin_us = now_us() - t0;
+    return rc;
 }
 
 int qe_schedule_plan(qe_engine* e, const double* eps, const double* lr, int64_t count) {
@@ -1442,7 +1452,10 @@ int64_t qe_rollout_chunk_limit(qe_engine* e, qe_env* env, int32_t learn) {
 int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats) {
     if (!e || slot < 0 || slot > 1) return fail(QE_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(e->device));
-    return rollout_end(e, e->slots[slot], stats);
+    const double t0 = now_us();
+    const int rc = rollout_end(e, e->slots[slot], stats);
+    if (stats) { stats->host_begin_us = e->host_begin_us; stats->host_end_us = now_us() - t0; }
+    return rc;
 }
 
 int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int32_t mode,
@@ -1452,6 +1465,34 @@ int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, cons
     if (steps == 0) return QE_OK;
     if (int rc = begin(e, env, steps, eps, lr, mode, 1, trace_actions, 0)) return rc;
     return rollout_end(e, e->slots[0], stats);
+}
+
+int64_t qe_rollout_fused(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int32_t mode,
+                         qe_rollout_stats* stats, int64_t cap, int32_t* ep_step, float* ep_ret, float* ret_sum,
+                         int32_t* obs, uint32_t* aux, float* agent_rewards) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (e) e->ep_host.clear();
+    if (ret_sum) *ret_sum = 0.0f;
+    if (steps == 0) return 0;
+    const double t0 = now_us();
+    if (int rc = begin(e, env, steps, eps, lr, mode, 1, nullptr, 0)) return rc;
+    const double t1 = now_us();
+    if (int rc = rollout_end(e, e->slots[0], stats)) return rc;
+    const int64_t n = (int64_t)e->ep_host.size();
+    float sum = 0.0f;  // sequential float32 accumulation: sum(reward_history) of single_thread_runtime.py:67
+    for (int64_t k = 0; k < n; ++k) {
+        const float r = e->ep_host[(size_t)k].second;
+        sum += r;
+        if (k < cap) {
+            if (ep_step) ep_step[k] = (int32_t)(e->ep_host[(size_t)k].first >> 32);
+            if (ep_ret) ep_ret[k] = r;
+        }
+    }
+    if (ret_sum) *ret_sum = sum;
+    if (obs || agent_rewards) if (int rc = qe_env_observe(env, obs, nullptr, agent_rewards)) return rc;
+    if (aux) if (int rc = qe_env_aux(env, aux)) return rc;
+    if (stats) { stats->host_begin_us = t1 - t0; stats->host_end_us = now_us() - t1; }
+    return n;
 }
 
 int qe_evaluate(qe_engine* e, qe_env* env, int64_t steps, qe_rollout_stats* stats) {

@@ -34,6 +34,7 @@ class DeviceVecEnv:
         self._algo = None
         self._lib = None
         self._resident = None  # (states array, rewards array) of the state dict that mirrors the device
+        self._chunk_limits = {}
 
     def __len__(self) -> int:
         return self.num_agents
@@ -63,6 +64,7 @@ class DeviceVecEnv:
             raise ValueError(msg)
         self.close()
         self._resident = None
+        self._chunk_limits = {}
         self._lib = _lib.load()
         _lib.check(self._lib.qe_env_create(C.byref(self._h), algorithm.handle, self.num_agents,
                                            C.byref(self._params)))
@@ -109,6 +111,20 @@ class DeviceVecEnv:
             arr.flags.writeable = False
         self._resident = (obs, rewards)
         return {"states": states, "infos": [{}] * self.num_agents, "rewards": rewards, "aux": aux}
+
+    def adopt_state(self, obs, rewards, aux) -> dict:
+        """:meth:`state_dict` from arrays the engine has just filled (no further device round trip)."""
+        for arr in (obs, rewards, aux):
+            arr.flags.writeable = False
+        self._resident = (obs, rewards)
+        return {"states": obs, "infos": [{}] * self.num_agents, "rewards": rewards, "aux": aux}
+
+    def chunk_limit(self, learn: bool) -> int:
+        """Vector steps one launch may take on this environment (``qe_rollout_chunk_limit``; cached)."""
+        key = bool(learn)
+        if key not in self._chunk_limits:
+            self._chunk_limits[key] = max(1, int(self._lib.qe_rollout_chunk_limit(self._algo.handle, self._h, 1 if learn else 0)))
+        return self._chunk_limits[key]
 
     def is_resident(self, state_dict) -> bool:
         """True if ``state_dict`` is the (unmodified) one :meth:`state_dict` produced last and the device

@@ -36,6 +36,13 @@ class BaseSchedule:
             self.update(n_updates)
         return out
 
+    def advance_into(self, n_updates: int, count: int, out) -> None:
+        """The same values written into ``out[0:count]`` (any indexable buffer, e.g. a ctypes array): the
+        form a short fused rollout uses, no NumPy set-up cost."""
+        for t in range(count):
+            out[t] = self.get_value()
+            self.update(n_updates)
+
 
 class ConstantSchedule(BaseSchedule):
     """``schedules/constant_schedule.py:6-13``."""
@@ -49,6 +56,9 @@ class ConstantSchedule(BaseSchedule):
     def advance_values(self, n_updates: int, count: int) -> np.ndarray:
         return np.full(count, self.get_value(), dtype=np.float64)
 
+    def advance_into(self, n_updates: int, count: int, out) -> None:
+        out[0:count] = [self.get_value()] * count
+
 
 class ExponentialSchedule(BaseSchedule):
     """``v <- max(v * decay_rate**steps, min_value)`` (``schedules/exponential_schedule.py:22-31``)."""
@@ -59,6 +69,17 @@ class ExponentialSchedule(BaseSchedule):
 
     def update(self, steps: int) -> None:
         self.set_value(max(self.get_value() * (self.decay_rate**steps), self.min_value))
+
+    def advance_into(self, n_updates: int, count: int, out) -> None:
+        # the same float64 operations in the same order as `update`, without a method call per step
+        v, lo, f = self.get_value(), self.min_value, self.decay_rate**n_updates
+        if v == lo and 0.0 <= f <= 1.0 and lo >= 0.0:  # at the floor: max(lo * f, lo) == lo from here on
+            out[0:count] = [lo] * count
+            return
+        for t in range(count):
+            out[t] = v
+            v = max(v * f, lo)
+        self.set_value(v)
 
     def advance_values(self, n_updates: int, count: int) -> np.ndarray:
         v, lo, f = float(self.get_value()), float(self.min_value), float(self.decay_rate**n_updates)
@@ -90,6 +111,13 @@ class LinearSchedule(BaseSchedule):
 
     def update(self, steps: int) -> None:
         self.set_value(self.get_value() + steps * self.decay_rate)
+
+    def advance_into(self, n_updates: int, count: int, out) -> None:
+        v, inc = self.get_value(), n_updates * self.decay_rate
+        for t in range(count):
+            out[t] = v
+            v = v + inc
+        self.set_value(v)
 
     def advance_values(self, n_updates: int, count: int) -> np.ndarray:
         v, inc = float(self.get_value()), float(n_updates * self.decay_rate)

@@ -81,6 +81,8 @@ typedef struct qe_rollout_stats {
     int64_t dominant_launches; /* how many launches were sampled (<= 256, spread over the call) */
     int64_t dominant_env_steps; /* env-steps (agent x vector step) those sampled launches processed */
     double device_clock_ms;  /* persistent path: in-kernel constant-rate clock, launch start -> results published (0 otherwise) */
+    double host_begin_us;    /* host time spent inside qe_rollout_begin (enqueue) ... */
+    double host_end_us;      /* ... and inside qe_rollout_end (wait + result hand-over) */
 } qe_rollout_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -172,6 +174,14 @@ int qe_rollout(qe_engine* e, qe_env* env, int64_t steps, const double* eps, cons
 int qe_rollout_begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr,
                      int32_t mode, int32_t slot);
 int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats);
+/* One call for a whole run_steps body (single_thread_runtime.py:63-75) that fits one launch: qe_rollout +
+ * the episode log (first `cap` entries into ep_step / ep_ret; the rest stays available through
+ * qe_episode_log) + the float32 running sum of the returns in log order (:67) + what the resume dict
+ * needs (observations, env-internal state, running per-agent returns; any may be NULL).  Returns the
+ * number of episodes that ended, or a negative qe_status. */
+int64_t qe_rollout_fused(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int32_t mode,
+                         qe_rollout_stats* stats, int64_t cap, int32_t* ep_step, float* ep_ret, float* ret_sum,
+                         int32_t* obs, uint32_t* aux, float* agent_rewards);
 /* Largest `steps` of one qe_rollout / qe_rollout_begin / qe_evaluate call on this environment for which
  * the episode log cannot overflow even if every agent finishes an episode in every step (the caller
  * chops longer calls: single_thread_runtime.py:63-64 has no such limit). */

@@ -32,7 +32,7 @@ def test_struct_layouts_match_the_header():
     from dist_classicrl_amd import _lib
 
     assert ctypes.sizeof(_lib.EnvParams) == 32
-    assert ctypes.sizeof(_lib.RolloutStats) == 72
+    assert ctypes.sizeof(_lib.RolloutStats) == 88
 
 
 def test_no_cpu_fallback():

@@ -95,6 +95,9 @@ def test_ranks_sharing_one_gpu_match_the_simulated_protocol(tmp_path, world, N_P
 
     for r in ranks:
         assert np.array_equal(obs[r], runs[r].obs), "agents took a different path than in the simulation"
-        assert np.allclose(got[r], runs[r].q, rtol=1e-5, atol=1e-6)
+        bad = ~np.isclose(got[r], runs[r].q, rtol=1e-5, atol=1e-6)
+        assert not bad.any(), (f"rank {r}: {int(bad.sum())} cells differ from the simulation, largest difference "
+                               f"{np.abs(got[r] - runs[r].q).max():.3g}, first at {np.argwhere(bad)[:5].tolist()}: "
+                               f"{got[r][bad][:5]} vs {runs[r].q[bad][:5]}")
         assert np.allclose(got[0], got[r], rtol=1e-5, atol=1e-6)
     assert np.count_nonzero(got[0]) > 500 and not np.array_equal(obs[0], obs[1])

@@ -20,12 +20,15 @@ env = HashTabularEnv(128, 1_000_000, 16, seed=1)
 rt = GpuRolloutQLearning(algo, ExponentialSchedule(0.1, 1e-5, 0.995), ExponentialSchedule(1.0, 0.01, 0.995))
 _, _, _, sd = rt.run_steps(2000, env, None)
 reps = 300
-dev = 0.0
+dev = hb = he = 0.0
 t0 = time.perf_counter()
 for _ in range(reps):
     _, _, _, sd = rt.run_steps(steps, env, sd)
     dev += rt.last_stats["device_clock_ms"] if host_block else rt.last_stats["kernel_ms"]
+    hb += rt.last_stats["host_begin_us"]; he += rt.last_stats["host_end_us"]
 per = (time.perf_counter() - t0) / reps * 1e6
+print(f"   inside qe_rollout_begin {hb / reps:.1f} us, inside qe_rollout_end {he / reps:.1f} us, "
+      f"Python around them {per - (hb + he) / reps:.1f} us")
 print(f"steps={steps} event_timing={timing} host_block={host_block}: {per:.1f} us per run_steps call, "
       f"{dev / reps * 1e3:.1f} us of it on the device ({dev / reps * 1e3 / steps:.2f} us/step) -> "
       f"{per - dev / reps * 1e3:.1f} us fixed; {steps * 128 / per:.1f} M env-steps/s")
