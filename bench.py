@@ -4,12 +4,15 @@
 around the ``train``-equivalent with validation off (:222-249), benchmark-default hyper-parameters
 (gamma 0.99, lr Exp(0.1 -> 1e-5, 0.995), epsilon Exp(1.0 -> 0.01, 0.995), :53-59).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--agents A]
 
 One "step" = one vector step of the fused loop (select -> env.step -> learn for every agent).
-N > 1: launched by ``torch.distributed.run``, one rank per GPU; every GPU owns its own agents and a
-table replica and exchanges Q-deltas every 100 steps over RCCL (weak scaling: per-GPU work fixed).
-Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU; every GPU owns its own agents and a table replica and exchanges Q-deltas every
+100 steps over RCCL (weak scaling: per-GPU work fixed).  The ranks are either started by the caller
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: RANK / WORLD_SIZE in the
+environment) or, when bench.py is run plainly with ``--gpus N``, by bench.py itself as child processes
+(like the reference's harness starts its own ranks, throughput_benchmark.py:326-366).  Rank 0 prints ONE
+JSON line.
 """
 
 from __future__ import annotations
@@ -17,6 +20,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import platform
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -41,6 +47,7 @@ WORKLOADS = {
 }
 PUBLISHED_TICTACTOE_SINGLE_THREAD_128 = 22_300.0  # benchmark_results/single_thread_128_agents.json
 SYNC_EVERY = 100  # BASELINE.json configs[3]: all-reduce of Q-deltas every 100 steps
+ROOFLINE_SAMPLES = 8  # further launches of the same K steps, bracketed by HIP events
 
 
 def algorithmic_bytes_per_env_step(actions: int, masked: bool, esize: int = 4) -> int:
@@ -49,6 +56,18 @@ def algorithmic_bytes_per_env_step(actions: int, masked: bool, esize: int = 4) -
     if masked:
         b += 2 * ((actions + 7) // 8)
     return b
+
+
+def cpu_description():
+    model = ""
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"model": model or platform.processor(), "logical_cores": os.cpu_count()}
 
 
 def cpu_baseline(wl, budget_s: float = 12.0):
@@ -85,6 +104,7 @@ def cpu_baseline(wl, budget_s: float = 12.0):
         "value": float(np.median(rates)), "unit": "env-steps/s", "cores": 1, "kind": "port",
         "sample": f"{len(rates)} x {block} vector steps x {n} agents after {warm} warm-up steps, "
                   "oracle/qlearn_oracle.py (interpreted NumPy restatement of single_thread, fp64 table)",
+        "cpu": cpu_description(),
     }
     try:
         if wl.get("env") == "tictactoe":
@@ -98,15 +118,36 @@ def cpu_baseline(wl, budget_s: float = 12.0):
     return out
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as child processes (the parent never
+    touches a GPU) and pass their one JSON line through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env, check=False).returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--agents", type=int, default=None, help="agents per GPU (default: the workload's)")
     ap.add_argument("--mode", default="iter", choices=["iter", "vec"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend of the ranks; gloo + fewer GPUs than ranks (ranks then share GPUs) is a "
+                         "rehearsal of the N > 1 path on a small box, not a measurement")
     args = ap.parse_args()
+
+    launched = "RANK" in os.environ  # started by torch.distributed.run (also with a single rank)
+    if args.gpus > 1 and not launched:
+        raise SystemExit(launch_ranks(args))
 
     # stdout carries the ONE JSON line and nothing else: libraries that print banners to file
     # descriptor 1 (RCCL does at communicator creation) are sent to stderr until the line is printed
@@ -114,25 +155,31 @@ def main() -> None:
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.agents:
+        wl["agents"] = args.agents
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with a single rank)
+    use_dist = launched
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus:  # an inconsistent environment: refuse rather than report a wrong n_gpus
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE says {n_gpus} rank(s) were started\n")
+        raise SystemExit(2)
     if use_dist:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus:
-        sys.stderr.write(f"bench.py: --gpus {args.gpus} but {n_gpus} rank(s) were started; launch N > 1 with\n"
-                         f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                         f"--master-port P bench.py --gpus {args.gpus} ...\n")
-        raise SystemExit(2)
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
 
+    from dist_classicrl_amd import _lib
     from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
     from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
     from dist_classicrl_amd.environments import HashTabularEnv, TicTacToeEnv
@@ -174,7 +221,16 @@ def main() -> None:
         except ZeroDivisionError:
             return env.state_dict()
 
-    sd = run_steps(max(1, args.warmup), None)  # untimed warm-up (also resets the env)
+    # Untimed warm-up: W vector steps, taken in a few calls so that every per-call path of the timed call
+    # (engine slots, page-locked result block, the Python around them) has run before the clock starts.
+    # The timed launch carries no HIP events (the engine clocks it in-kernel): an event pair costs ~7 us
+    # of a 20-step call.
+    algo.set_engine_option(_lib.OPT_EVENT_TIMING, 0)
+    w = max(1, args.warmup)
+    pieces = [w // 4] * 3 + [w - 3 * (w // 4)] if w >= 8 else [1] * w
+    sd = None
+    for k in pieces:
+        sd = run_steps(k, sd)
     sync_all()
     t0 = time.perf_counter()
     sd = run_steps(args.steps, sd)  # EXACTLY K timed vector steps
@@ -187,22 +243,54 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # Roofline samples: further launches of the same K steps (the training simply continues), each
+    # bracketed by HIP events on the engine's stream.
+    algo.set_engine_option(_lib.OPT_EVENT_TIMING, 1)
+    persistent = stats["launches"] < args.steps or args.steps == 1 and n <= 512 and wl["actions"] <= 64
+    samples = []
+    for _ in range(ROOFLINE_SAMPLES if persistent else 1):
+        sd = run_steps(args.steps, sd)
+        samples.append(dict(rt.last_stats))
+    sync_all()
     if rank != 0:
         dist.destroy_process_group()
         return
 
     env_steps = args.steps * n * n_gpus
     bpe = algorithmic_bytes_per_env_step(wl["actions"], wl["masked"])
-    launches = max(1, stats["dominant_launches"])
-    avg_launch_s = stats["dominant_ms"] / launches / 1e3
-    units_per_launch = stats["dominant_env_steps"] / launches
-    achieved = bpe * units_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    persistent = stats["launches"] < args.steps
-    traffic = None  # HBM bytes per launch from the PMC passes kept under profiles/ (same kernel, same workload)
+    if persistent:
+        # one launch per (chunk of a) call: the launch IS the step loop
+        kernel = "k_rollout_lane"
+        launches = sum(s["dominant_launches"] for s in samples)
+        launch_s = sum(s["dominant_ms"] for s in samples) / max(1, launches) / 1e3
+        units_per_launch = sum(s["dominant_env_steps"] for s in samples) / max(1, launches)
+        if launches == 0:  # (replica-exchange calls time every eighth launch only: fall back to the in-kernel clock)
+            launches = sum(s["launches"] for s in samples)
+            launch_s = sum(s["device_clock_ms"] for s in samples) / max(1, launches) / 1e3
+            units_per_launch = args.steps * n * len(samples) / max(1, launches)
+        achieved = bpe * units_per_launch / launch_s / 1e9 if launch_s > 0 else 0.0
+        timing = (f"HIP events on the engine's stream around {launches} further launches of the same {args.steps} steps right "
+                  "after the timed region; the timed launch itself carries no events (in-kernel clock: device_region_ms)")
+        kernel_note = "one launch runs all K vector steps on one CU: a latency-bound dependent chain per step, not a bandwidth-bound kernel"
+    else:
+        # several kernels per vector step: the roofline figure is the WHOLE step (algorithmic bytes of one
+        # vector step / device time of one vector step, HIP events around the region); the engine
+        # additionally samples the first kernel of the step (k_step_fast), reported in the note
+        s0 = samples[0]
+        kernel = "vector step (k_step_fast + token rounds + k_step_slow + k_advance)"
+        launch_s = s0["kernel_ms"] / args.steps / 1e3
+        launches = args.steps
+        units_per_launch = n
+        achieved = bpe * n / launch_s / 1e9 if launch_s > 0 else 0.0
+        timing = "HIP events around the whole stream region of one further call of the same K steps"
+        kernel_note = (f"k_step_fast alone: {s0['dominant_ms'] / max(1, s0['dominant_launches']) * 1e3:.2f} us per launch over "
+                       f"{s0['dominant_launches']} sampled launches; per-kernel split: profiles/")
+    traffic_profile = None  # HBM bytes from the PMC passes kept under profiles/ (NOT measured in this run)
     try:
-        prof = json.loads((ROOT / "profiles" / "r01h_traffic.json").read_text()).get(args.workload)
-        if prof and persistent and "persistent" in prof["kernel"]:
-            traffic = prof["traffic_bytes_per_env_step"] * units_per_launch
+        prof = json.loads((ROOT / "profiles" / "r02_traffic.json").read_text()).get(args.workload)
+        if prof:
+            traffic_profile = {"file": "profiles/r02_traffic.json", **prof}
     except (OSError, ValueError, KeyError):
         pass
     line = {
@@ -226,34 +314,51 @@ def main() -> None:
                         f"{', episode returns as array' if rt.history_type == 'array' else ''}",
             "agents_per_gpu": n, "states": wl["states"], "actions": wl["actions"],
             "sync_every": SYNC_EVERY if use_dist else None,
-            "parallelism": f"agents sharded x{n_gpus}, table replicas + RCCL delta all-gather" if n_gpus > 1 else "1 GPU",
+            "parallelism": (f"agents sharded x{n_gpus}, table replicas + {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} "
+                            "delta all-gather") if n_gpus > 1 else "1 GPU",
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_rollout_persistent" if persistent else "k_step_fast",
+            "kernel": kernel,
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic,
+            "step_frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "traffic_from_profile": traffic_profile,
             "alg_bytes_per_env_step": bpe,
             "units_per_launch": units_per_launch,
-            "avg_launch_us": avg_launch_s * 1e6,
-            "launches_sampled": stats["dominant_launches"],
+            "avg_launch_us": launch_s * 1e6,
+            "launches_sampled": launches,
+            "timing": timing,
+            "note": kernel_note,
         },
-        "device_region_ms": stats["kernel_ms"],
+        "device_region_ms": stats.get("device_clock_ms") or stats["kernel_ms"],
+        "host_enqueue_us": stats.get("host_begin_us"),
+        "host_wait_us": stats.get("host_end_us"),
         "kernel_launches": stats["launches"],
         "episodes": int(stats["episodes"]),
         "contested_agent_steps": stats["involved"],
+        # the fields of the reference's result files (throughput_benchmark.py:251-259, 310-317)
+        "reference_fields": {
+            "runtime": "gpu_rollout" if n_gpus == 1 else "gpu_rollout_replicas",
+            "total_steps": args.steps, "effective_steps": args.steps * n * n_gpus, "elapsed_time": elapsed,
+            "throughput": env_steps / elapsed, "step_multiplier": n * n_gpus, "num_agents": n,
+            "num_processes": n_gpus, "timestamp": time.strftime("%Y-%m-%dT%H:%M:%S"),
+        },
     }
     if not args.no_cpu_baseline and n_gpus == 1:
         line["cpu_baseline"] = cpu_baseline(wl)
         line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        if "compiled_c_value" in line["cpu_baseline"]:
+            line["speedup_vs_compiled_c_one_core"] = line["value"] / line["cpu_baseline"]["compiled_c_value"]
     if args.workload == "tictactoe" and n_gpus == 1:
         line["vs_reference_published_single_thread_128_agents_i7_11700K"] = (
             line["value"] / PUBLISHED_TICTACTOE_SINGLE_THREAD_128)
     if use_dist:
-        line["delta_sync"] = {"syncs": rt.delta_sync.syncs, "bytes_received_per_gpu": rt.delta_sync.bytes_exchanged}
+        line["delta_sync"] = {"syncs": rt.delta_sync.syncs, "bytes_received_per_gpu": rt.delta_sync.bytes_exchanged,
+                              "sync_every": SYNC_EVERY, "collective": "all_gather_into_tensor of (cell, delta) logs"}
     sys.stdout.flush()
     os.dup2(json_fd, 1)
     print(json.dumps(line), flush=True)

@@ -83,6 +83,8 @@ PROTOTYPES = {
     "qe_set_option": (C.c_int, [_P, C.c_int32, C.c_int64]),
     "qe_table_upload": (C.c_int, [_P, _P, C.c_int32]),
     "qe_table_download": (C.c_int, [_P, _P, C.c_int32]),
+    "qe_table_download_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "qe_table_upload_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "qe_table_cells": (C.c_int, [_P, _I32P, _I32P, C.c_int64, _F64P, C.c_int32]),
     "qe_table_dev": (_P, [_P]),
     "qe_table_row_stride": (C.c_int64, [_P]),
@@ -112,6 +114,7 @@ PROTOTYPES = {
     "qe_delta_log_reset": (C.c_int, [_P]),
     "qe_delta_apply_dev": (C.c_int, [_P, _P, C.c_int64]),
     "qe_delta_apply_skip_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64]),
+    "qe_delta_apply_sorted_dev": (C.c_int, [_P, _P, C.c_int64]),
     "qe_replay_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
     "qe_replay_destroy": (C.c_int, [_P]),
     "qe_replay_push": (C.c_int, [_P, _I64P, _I64P, _F64P, _I64P, _U8P, C.c_int64]),

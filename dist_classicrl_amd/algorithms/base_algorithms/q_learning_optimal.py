@@ -186,9 +186,36 @@ class OptimalQLearningBase:
         """``np.add.at`` semantics: duplicates accumulate, in index order (reference :235-250)."""
         self._cells(states, actions, values, 2)
 
+    _IO_CHUNK_BYTES = 64 << 20  # rows are streamed between HBM and the file in blocks of this size
+
     def save(self, filename):
-        """``np.save`` of the (S, A) table, the reference's on-disk format (:252-261)."""
-        np.save(filename, np.asarray(self.q_table))
+        """The (S, A) table as a ``.npy`` file, the reference's on-disk format (``np.save``, :252-261),
+        streamed from HBM block by block: no second copy of the table on the host."""
+        filename = str(filename)
+        if not filename.endswith(".npy"):
+            filename += ".npy"  # np.save appends the suffix too
+        rows_per = max(1, self._IO_CHUNK_BYTES // (self.action_size * self.dtype.itemsize))
+        with open(filename, "wb") as f:
+            np.lib.format.write_array_header_1_0(f, {"descr": np.lib.format.dtype_to_descr(self.dtype),
+                                                      "fortran_order": False,
+                                                      "shape": (self.state_size, self.action_size)})
+            block = np.empty((min(rows_per, self.state_size), self.action_size), dtype=self.dtype)
+            for first in range(0, self.state_size, rows_per):
+                k = min(rows_per, self.state_size - first)
+                _lib.check(self._lib.qe_table_download_rows(self._h, block.ctypes.data, first, k))
+                f.write(memoryview(block[:k]))
+
+    def load(self, filename):
+        """Counterpart of :meth:`save` (the reference has none: its users assign ``np.load(...)`` to
+        ``q_table``): streams a ``.npy`` table of this shape into HBM, casting to the table's dtype."""
+        src = np.load(filename, mmap_mode="r")
+        if src.shape != (self.state_size, self.action_size):
+            msg = f"{filename} holds a table of shape {src.shape}, expected {(self.state_size, self.action_size)}"
+            raise ValueError(msg)
+        rows_per = max(1, self._IO_CHUNK_BYTES // (self.action_size * self.dtype.itemsize))
+        for first in range(0, self.state_size, rows_per):
+            block = np.ascontiguousarray(src[first:first + rows_per], dtype=self.dtype)
+            _lib.check(self._lib.qe_table_upload_rows(self._h, block.ctypes.data, first, block.shape[0]))
 
     # ------------------------------------------------------------------ selection (:263-726)
     def _select(self, states, exploration_rate, deterministic, action_masks, numpy_variant=False):

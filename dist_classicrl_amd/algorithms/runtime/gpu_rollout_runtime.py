@@ -21,13 +21,14 @@ from dist_classicrl_amd.environments.device_envs import DeviceVecEnv
 from .base_runtime import BaseRuntime, _count_agents
 
 _SHORT_CALL = 64  # up to here the schedule values are produced by a plain Python loop (no NumPy set-up cost)
+_ShortSchedule = C.c_double * _SHORT_CALL  # (one array type for every short call: ctypes builds a type per length, slowly)
 
 
 def _schedule_values(schedule, n_updates, count):
     """The ``count`` values ``get_value(); update(n_updates); ...`` reads, as a ctypes double array
     (short calls) or a float64 ndarray; the schedule is left advanced (base_runtime.py:248,262-263)."""
     if count <= _SHORT_CALL:
-        out = (C.c_double * count)()
+        out = _ShortSchedule()
         into = getattr(schedule, "advance_into", None)
         if into is not None:
             into(n_updates, count, out)

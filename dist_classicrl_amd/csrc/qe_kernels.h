@@ -1781,6 +1781,20 @@ __global__ void k_delta_apply_skip(T* q, const DeltaEntry* e, int64_t count, int
     atomicAdd(q + e[i].cell, (T)e[i].delta);
 }
 
+// Deterministic form: the records arrive stably sorted by cell (the exchange sorts them: rank-major,
+// slot-minor order within a cell); the first record of every run of one cell adds the whole run
+// sequentially, so the float additions into a cell happen in a fixed order.
+template <typename T>
+__global__ void k_delta_apply_sorted(T* q, const DeltaEntry* e, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t cell = e[i].cell;
+    if (i > 0 && e[i - 1].cell == cell) return;
+    T v = q[cell];
+    for (int64_t j = i; j < count && e[j].cell == cell; ++j) v = v + (T)e[j].delta;
+    q[cell] = v;
+}
+
 // ---- experience replay ring (experience_replay.py): gather of sampled entries ---------------------
 __global__ void k_replay_gather(const int64_t* rs, const int64_t* ra, const double* rr, const int64_t* rn,
                                 const uint8_t* rd, const int64_t* idx, int64_t n, int64_t* s, int64_t* a,

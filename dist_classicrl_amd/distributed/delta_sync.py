@@ -33,9 +33,12 @@ import torch.distributed as dist
 
 class DeltaSync:
     def __init__(self, capacity: int, device, apply_fn, attach_fn=None, group=None, overlap: bool = True,
-                 stream=None, apply_skip_fn=None) -> None:
+                 stream=None, apply_skip_fn=None, apply_sorted_fn=None) -> None:
         self.stream = stream  # torch.cuda.Stream the engine runs on (None on CPU / current stream)
         self.apply_skip_fn = apply_skip_fn  # (entries, total, skip_begin, skip_end): one-launch form
+        # (entries sorted by cell, total): deterministic form -- every cell receives the other ranks'
+        # increments sequentially in (rank, slot) order instead of through float atomics in arrival order
+        self.apply_sorted_fn = apply_sorted_fn
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -73,7 +76,13 @@ class DeltaSync:
         if work is not None:
             work.wait()  # the current stream now waits for the collective; the host does not block
         g = self.gathered[buf]
-        if count == self.capacity and self.apply_skip_fn is not None:
+        if self.world == 1:
+            pass  # nobody else's records
+        elif self.apply_sorted_fn is not None:
+            others = torch.cat([g[r, :count] for r in range(self.world) if r != self.rank])
+            order = torch.sort(others[:, 0], stable=True).indices  # by cell; ties keep (rank, slot) order
+            self.apply_sorted_fn(others[order].contiguous(), int(others.shape[0]))
+        elif count == self.capacity and self.apply_skip_fn is not None:
             # full segments are contiguous: every rank's records except my own in ONE launch
             self.apply_skip_fn(g.reshape(-1, 2), count * self.world, count * self.rank, count * (self.rank + 1))
         elif count == self.capacity and self.world > 2:
@@ -123,8 +132,14 @@ class DeltaSync:
         if previous is not None:
             self._finish(*previous)
 
-def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overlap: bool = True) -> DeltaSync:
-    """Wire a :class:`DeltaSync` to a HIP engine living on the current CUDA device."""
+def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overlap: bool = True,
+                  deterministic: bool = True) -> DeltaSync:
+    """Wire a :class:`DeltaSync` to a HIP engine living on the current CUDA device.
+
+    ``deterministic`` (default): the other ranks' records are sorted by cell (torch, on the engine's
+    stream -- plumbing) and added by ``qe_delta_apply_sorted_dev`` in (rank, slot) order per cell, so a
+    replica is reproducible bit for bit; ``False`` adds them with float atomics in arrival order (one
+    launch, no sort)."""
     import ctypes as C
 
     from dist_classicrl_amd import _lib
@@ -148,6 +163,12 @@ def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overl
         _lib.check(lib.qe_delta_apply_skip_dev(algorithm.handle, C.c_void_p(entries.data_ptr()), int(total),
                                                int(skip_begin), int(skip_end)))
 
-    sync = DeltaSync(capacity, dev, apply_fn, attach_fn, group, overlap, stream, apply_skip_fn)
+    def apply_sorted_fn(entries, total):
+        _lib.check(lib.qe_delta_apply_sorted_dev(algorithm.handle, C.c_void_p(entries.data_ptr()), int(total)))
+        # (the sorted copy must outlive the kernel that reads it: keep it until the next exchange)
+        apply_sorted_fn.keep = entries
+
+    sync = DeltaSync(capacity, dev, apply_fn, attach_fn, group, overlap, stream, apply_skip_fn,
+                     apply_sorted_fn if deterministic else None)
     stream.wait_stream(torch.cuda.current_stream())  # buffer initialisation ran on the current stream
     return sync

@@ -114,6 +114,10 @@ int qe_set_option(qe_engine* e, int32_t option, int64_t value);
  * (rebind / copy back).  host buffers are C-contiguous (S, A) of `host_dtype`. */
 int qe_table_upload(qe_engine* e, const void* host, int32_t host_dtype);
 int qe_table_download(qe_engine* e, void* host, int32_t host_dtype);
+/* Streaming form for save / load (:252-261; the table of BASELINE config 4 is 1.28 GB): rows
+ * [first_row, first_row + rows) as a C-contiguous (rows, A) block in the TABLE's dtype. */
+int qe_table_download_rows(qe_engine* e, void* host, int64_t first_row, int64_t rows);
+int qe_table_upload_rows(qe_engine* e, const void* host, int64_t first_row, int64_t rows);
 /* get_q_values / set_q_value(s) / add_q_values (:100-250); add follows np.add.at (duplicates
  * accumulate in index order). op: 0 = read into vals, 1 = write, 2 = add. */
 int qe_table_cells(qe_engine* e, const int32_t* states, const int32_t* actions, int64_t n,
@@ -211,6 +215,11 @@ int qe_delta_apply_dev(qe_engine* e, const void* dev_entries, int64_t count);
  * rank's own segment, which is already in its table -- in ONE launch. */
 int qe_delta_apply_skip_dev(qe_engine* e, const void* dev_entries, int64_t count, int64_t skip_begin,
                             int64_t skip_end);
+
+/* Deterministic form: `dev_entries` holds the OTHER ranks' records stably sorted by cell (so that within a
+ * cell they are in rank-major, slot-minor order); every cell receives its additions sequentially in that
+ * order -- no float atomics, the same result on every run. */
+int qe_delta_apply_sorted_dev(qe_engine* e, const void* dev_entries, int64_t count);
 
 /* ---- experience replay (algorithms/buffers/experience_replay.py:13-120; WIP and unused upstream) --
  * Ring buffer of (state, action, reward, next_state, done) in HBM.  Index SELECTION stays with the

@@ -55,10 +55,15 @@ class CHashRollout:
         self.step = 0
         self.lib.oc_reset(C.byref(self.cfg), _p(self.obs), _p(self.episode), _p(self.acc))
 
-    def run(self, eps, lr, *, trace=False, log_episodes=True):
+    def run(self, eps, lr, *, trace=False, log_episodes=True, delta_log=False):
+        """``delta_log=True`` adds ``"cells"`` / ``"deltas"``: one (cell = s * A + a, float32 increment) record
+        per agent and step, in (step, agent) order -- the content of the engine's delta log."""
         eps = np.ascontiguousarray(eps, dtype=np.float64)
         lr = np.ascontiguousarray(lr, dtype=np.float64)
         steps, n = eps.size, self.cfg.n
+        if delta_log:
+            d_cells, d_deltas = np.empty(steps * n, dtype=np.uint32), np.empty(steps * n, dtype=np.float32)
+            self.lib.oc_set_delta_log(_p(d_cells), _p(d_deltas), C.c_int64(steps * n))
         tr = np.empty((steps, n), dtype=np.int32) if trace else None
         cap = steps * n if log_episodes else 0
         es, ea = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
@@ -69,7 +74,11 @@ class CHashRollout:
                             _p(er), C.c_int64(cap), C.byref(cnt))
         self.step += steps
         k = min(cnt.value, cap)
-        return {"actions": tr, "history": er[:k].copy(), "ep_step": es[:k].copy(), "episodes": cnt.value}
+        out = {"actions": tr, "history": er[:k].copy(), "ep_step": es[:k].copy(), "episodes": cnt.value}
+        if delta_log:
+            self.lib.oc_set_delta_log(None, None, C.c_int64(0))
+            out["cells"], out["deltas"] = d_cells, d_deltas
+        return out
 
 
 def exp_schedule(v0, vmin, decay, n_updates, count):

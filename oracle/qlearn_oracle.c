@@ -99,19 +99,37 @@ static int select_action(const oc_cfg* c, const void* q, int i, int32_t obs, uin
     return -1;
 }
 
+/* Optional record of every update (cell, increment as float32) in (step, agent) order: what the engine's
+ * delta log holds for the replica exchange (csrc: log_delta). */
+static uint32_t* g_dlog_cell = 0;
+static float* g_dlog_delta = 0;
+static int64_t g_dlog_cap = 0, g_dlog_count = 0;
+void oc_set_delta_log(uint32_t* cells, float* deltas, int64_t cap) {
+    g_dlog_cell = cells; g_dlog_delta = deltas; g_dlog_cap = cap; g_dlog_count = 0;
+}
+int64_t oc_delta_log_count(void) { return g_dlog_count; }
+static void dlog_put(int64_t cell, float u) {
+    if (g_dlog_cell && g_dlog_count < g_dlog_cap) { g_dlog_cell[g_dlog_count] = (uint32_t)cell; g_dlog_delta[g_dlog_count] = u; }
+    if (g_dlog_cell) ++g_dlog_count;
+}
+
 /* one TD update in place; `m` already holds max_valid Q[s'] (ignored when terminated) */
 static void td_iter(const oc_cfg* c, void* q, int64_t cell, float r, double m, int term, double lr) {
     if (c->dtype) {
         double* p = (double*)q + cell;
         const double t = term ? 0.0 : c->gamma * m;
         const double y = (double)r + t, d = y - *p;
-        *p = *p + lr * d;
+        const double u = lr * d;
+        dlog_put(cell, (float)u);
+        *p = *p + u;
     } else {
         float* p = (float*)q + cell;
         const float g = (float)c->gamma, l = (float)lr;
         const float t = term ? 0.0f : g * (float)m;
         const float y = r + t, d = y - *p;
-        *p = *p + l * d;
+        const float u = l * d;
+        dlog_put(cell, u);
+        *p = *p + u;
     }
 }
 static double td_vec_inc(const oc_cfg* c, const void* q, int64_t cell, float r, double m, int term, double lr) {
@@ -159,6 +177,7 @@ int oc_rollout(const oc_cfg* c, void* q, int32_t* obs, uint32_t* episode, float*
                 inc[i] = td_vec_inc(c, q, (int64_t)obs[i] * c->A + act[i], rew[i], row_max(c, q, nxt[i]), term[i], lr[t]);
             for (int i = 0; i < n; ++i) { /* np.add.at: float64 add, rounded into the table dtype */
                 const int64_t cell = (int64_t)obs[i] * c->A + act[i];
+                dlog_put(cell, (float)inc[i]);
                 if (c->dtype) ((double*)q)[cell] += inc[i];
                 else ((float*)q)[cell] = (float)((double)((float*)q)[cell] + inc[i]);
             }
