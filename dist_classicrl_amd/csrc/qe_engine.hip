@@ -592,13 +592,13 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                                        std::is_same<Env, TttEnv>::value);
             const bool full = (int64_t)block == env->N;  // every lane of the agents' wavefronts holds an agent
             if (HAS_LEAN && lean && block <= 128 && !c.dlog && full)  // (+ one draw-producing wavefront per wavefront of agents)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(2 * block), 0,
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
                                    e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if (HAS_LEAN && lean && block <= 128 && !c.dlog)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, false>), dim3(1), dim3(2 * block), 0,
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, false>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
                                    e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if (HAS_LEAN && lean && block <= 128)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, false>), dim3(1), dim3(2 * block), 0,
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, false>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
                                    e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else
                 hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, LANE_MAX_AGENTS, MK, 0, false, false>), dim3(1), dim3(block), 0, e->stream,

@@ -238,7 +238,7 @@ __device__ __forceinline__ void step_barrier() {
 // FULL: every lane of the agents' wavefronts holds an agent (N is a multiple of 64), so "this lane is
 // active" is a per-wavefront fact and the per-agent sections need no exec-mask bookkeeping.
 template <typename T, class Env, int NV, int CAP, bool MASKED, int LEAN = 0, bool HELP = false, bool FULL = false>
-__global__ __launch_bounds__(HELP ? 2 * CAP : CAP) void k_rollout_lane(InlineSched /*at offset 0 of the kernarg segment*/,
+__global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSched /*at offset 0 of the kernarg segment*/,
                                                                        Ctx<T> c, EnvCtx ev, long long steps, int flags) {
     using M = typename LaneMask<NV>::type;
     constexpr int NLOAD = NV * (int)(sizeof(T) / 4);  // 16-byte loads of one row gather
@@ -259,11 +259,15 @@ __global__ __launch_bounds__(HELP ? 2 * CAP : CAP) void k_rollout_lane(InlineSch
     if (threadIdx.x == 0) for (int k = 8; k < 24; ++k) c.vinc[k] = 0.0;
 #endif
     const int tid = threadIdx.x;
-    // agents' wavefronts first, then (HELP) as many draw-producing wavefronts
-    const int n_main = HELP ? (int)(blockDim.x >> 1) : (int)blockDim.x;
-    const bool helper = HELP && __builtin_amdgcn_readfirstlane(tid) >= n_main;  // (uniform per wavefront)
-    const int i = helper ? tid - n_main : tid;
-    const bool active = FULL ? !helper : (!helper && i < c.N);
+    // Agents' wavefronts first, then (HELP) as many draw-producing wavefronts, then wavefronts that only
+    // lend their lanes to the ordered path of contested steps (slow_body spreads over the whole block: with
+    // one lane group per involved agent its rounds stay in registers) and otherwise just keep the barriers.
+    const int n_main = HELP ? (int)((c.N + 63) & ~63ll) : (int)blockDim.x;
+    const int wave_tid = __builtin_amdgcn_readfirstlane(tid);  // (uniform per wavefront)
+    const bool helper = HELP && wave_tid >= n_main && wave_tid < 2 * n_main;
+    const bool worker = HELP && wave_tid >= 2 * n_main;
+    const int i = helper ? tid - n_main : (worker ? 0 : tid);
+    const bool active = FULL ? !(helper || worker) : (!(helper || worker) && i < c.N);
     const int ii = i < c.N ? i : 0;
     Pending<T> p;
     p.n = c.n[ii];
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(HELP ? 2 * CAP : CAP) void k_rollout_lane(InlineSch
                         }
                         barrier_lds();
                         if (tid < CAP / 32) lds.def_bits[tid] = 0u;
-                        slow_body<T, Env, CAP, PERSIST_CACHE_BYTES, 0>(
+                        slow_body<T, Env, CAP, PERSIST_CACHE_BYTES, NV>(
                             cc, ev, FLAG_NO_STAMPS | FLAG_LEARN | FLAG_PRESTAGED, t, n_def, lds.slow);
                     } else {
                         if (mine_def) {
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(HELP ? 2 * CAP : CAP) void k_rollout_lane(InlineSch
                         }
                         __syncthreads();
                         (void)build_involved_list(cc, lds.slow.scan);  // == n_def agents
-                        slow_body<T, Env, CAP, PERSIST_CACHE_BYTES, 0>(cc, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
+                        slow_body<T, Env, CAP, PERSIST_CACHE_BYTES, NV>(cc, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
                     }
                     __syncthreads();
                 } else {
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(HELP ? 2 * CAP : CAP) void k_rollout_lane(InlineSch
         lds.wt[(t + 3) & 3][w_prev] = -1;     // (t-1 mod 4; lanes without an entry write the dump slot)
         if (tid == 0) lds.busy[(t + 3) & 3] = 0u;  // flag of step t-1: every wave has read it since
         asm volatile("" ::: "memory");  // the gather stays behind every store of this step (vmcnt counts in order)
-        if (!helper && !QX(0)) load_row_lane<NV>(row, c.q, p.n);
+        if (!helper && !worker && !QX(0)) load_row_lane<NV>(row, c.q, p.n);
         asm volatile("" ::: "memory");
         if (active && !QX(2)) stale = bookkeeping(t + 1, true);
         QL_STAMP(1);

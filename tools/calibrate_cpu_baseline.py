@@ -4,7 +4,7 @@ stand-in for the reference's single_thread runtime.
 
     PYTHONPATH=/root/reference/src PYTHONDONTWRITEBYTECODE=1 python tools/calibrate_cpu_baseline.py
 """
-import sys, time
+import json, os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import numpy as np
@@ -40,6 +40,12 @@ def bench(make, n, steps=400, warm=50):
     return steps * n / (time.perf_counter() - t0)
 
 
+try:
+    os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[-1]})  # one core, like single_thread mode
+except (AttributeError, OSError):
+    pass
+ROUNDS = 9
+results = {}
 for n, S, A, masked in [(128, 1_000_000, 16, False), (128, 10_000, 8, False), (1024, 1_000_000, 64, True)]:
     def ref():
         algo = OptimalQLearningBase(S, A, 0.99, seed=0)
@@ -55,8 +61,16 @@ for n, S, A, masked in [(128, 1_000_000, 16, False), (128, 10_000, 8, False), (1
             HashTabularEnv(n, S, A, seed=1, masked=masked)
     steps = 400 if n <= 128 else 60
     rs, os_ = [], []
-    for _ in range(5):  # interleaved rounds: machine noise hits both sides alike
+    for _ in range(ROUNDS):  # interleaved rounds: machine noise hits both sides alike
         rs.append(bench(ref, n, steps))
         os_.append(bench(ora, n, steps))
     r, o = np.median(rs), np.median(os_)
     print(f"n={n} S={S} A={A} masked={masked}: reference {r:,.0f} env-steps/s, oracle {o:,.0f} env-steps/s, ratio {o / r:.3f}")
+    results[f"n{n}_S{S}_A{A}{'_masked' if masked else ''}"] = {
+        "reference_env_steps_per_s": [float(x) for x in rs], "oracle_env_steps_per_s": [float(x) for x in os_],
+        "median_ratio_oracle_over_reference": float(o / r),
+        "per_round_ratio": [float(b / a) for a, b in zip(rs, os_)]}
+out = Path(__file__).resolve().parents[1] / "profiles" / "r02_cpu_calibration.json"
+json.dump({"tool": "tools/calibrate_cpu_baseline.py (build container, one pinned core, interleaved rounds)",
+           "rounds": ROUNDS, "results": results}, open(out, "w"), indent=1)
+print("written", out)

@@ -6,7 +6,7 @@ import shutil
 import sys
 from pathlib import Path
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = Path("gpurun_out") / f"prof_{tag}"
 dst = Path("profiles")
 
@@ -39,19 +39,20 @@ def pmc_sum(group, counter, kernel_substr):
     return total, launches
 
 
-kern = "k_rollout_persistent"
+kern = "k_rollout_lane"
 fetch, n1 = pmc_sum("FETCH_SIZE", "FETCH_SIZE", kern)
 write, _ = pmc_sum("WRITE_SIZE", "WRITE_SIZE", kern)
 hit, _ = pmc_sum("TCC_HIT_sum_TCC_MISS_sum", "TCC_HIT_sum", kern)
 miss, _ = pmc_sum("TCC_HIT_sum_TCC_MISS_sum", "TCC_MISS_sum", kern)
 line = bench_line(src / "headline_stats.log")
-env_steps = (line["steps"] + line["warmup"]) * line["config"]["agents_per_gpu"]  # all launches of the process
+# all launches of the process: warm-up, the timed call and bench.py's 8 event-timed sample calls
+env_steps = (line["steps"] * (1 + line["roofline"]["launches_sampled"] // max(1, line["kernel_launches"])) + line["warmup"]) * line["config"]["agents_per_gpu"]
 traffic = 2.0 * fetch * 1024 + write * 1024  # KB counters; gfx950 FETCH_SIZE halves 16-B-per-lane loads
 out = {
     "headline": {
         "command": "rocprofv3 --kernel-trace --pmc <counter group> --output-format csv -- python3 bench.py --steps 20000 "
                    "--warmup 2000 --no-cpu-baseline (one pass per group: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)",
-        "kernel": "k_rollout_persistent<float, HashEnv, 4, 512, 1>",
+        "kernel": "k_rollout_lane<float, HashEnv, 4, 128, false, 1, true, true>",
         "launches": n1,
         "env_steps_all_launches": env_steps,
         "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
