@@ -118,6 +118,7 @@ PROTOTYPES = {
     "qe_replay_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
     "qe_replay_destroy": (C.c_int, [_P]),
     "qe_replay_push": (C.c_int, [_P, _I64P, _I64P, _F64P, _I64P, _U8P, C.c_int64]),
+    "qe_replay_attach": (C.c_int, [_P, _P]),
     "qe_replay_len": (C.c_int64, [_P]),
     "qe_replay_position": (C.c_int64, [_P]),
     "qe_replay_full": (C.c_int32, [_P]),

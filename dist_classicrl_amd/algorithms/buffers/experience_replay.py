@@ -89,6 +89,15 @@ class ExperienceReplay:
                                             _lib.ptr(r, C.c_double), _lib.ptr(n, C.c_int64),
                                             _lib.ptr(d, C.c_uint8), s.size))
 
+    def attach(self, algorithm) -> None:
+        """Wire the ring to ``algorithm``'s fused rollouts: every transition of every agent and vector step
+        is pushed device to device, in (step, agent) order -- what a host loop calling :meth:`push` after
+        every ``env.step`` would store."""
+        _lib.check(self._lib.qe_replay_attach(algorithm.handle, self._h))
+
+    def detach(self, algorithm) -> None:
+        _lib.check(self._lib.qe_replay_attach(algorithm.handle, None))
+
     # ------------------------------------------------------------------ sample (:88-109)
     def _indices(self, batch_size: int) -> np.ndarray:
         return self.rng.choice(self.capacity if self.full else self.position, batch_size, replace=False)

@@ -195,7 +195,10 @@ struct RolloutSlot {
     }
 };
 
+struct qe_replay;
+
 struct qe_engine {
+    qe_replay* replay = nullptr;  // ring the fused rollouts push their transitions into (qe_replay_attach)
     int device = 0;
     int dtype = QE_F32;
     int64_t S = 0;
@@ -252,6 +255,18 @@ struct qe_engine {
     hipStream_t copy_stream = nullptr;  // result read-back beside the compute stream
     RolloutSlot slots[2];               // two rollouts may be in flight (begin k+1 before end k)
     size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
+};
+
+struct qe_replay {
+    int device = 0;
+    int64_t capacity = 0, position = 0;
+    bool full = false;
+    DevBuf<int64_t> s, a, n, idx, o_s, o_a, o_n;
+    DevBuf<double> r, o_r;
+    DevBuf<uint8_t> d, o_d;
+    DevBuf<unsigned> bad;
+    hipStream_t stream = nullptr;
+    qe_engine* attached = nullptr;  // engine whose fused rollouts push into this ring
 };
 
 struct qe_env {
@@ -534,6 +549,13 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     if (e->dlog && learn) {
         c.dlog = e->dlog; c.dlog_base = e->dlog_count; c.dlog_cap = e->dlog_cap;
     }
+    if (e->replay && learn) {  // device-to-device push of every transition (experience_replay.py:68-86)
+        qe_replay* rb = e->replay;
+        c.rp = ReplayDev{rb->s.p, rb->a.p, rb->n.p, rb->r.p, rb->d.p, (long long)rb->capacity, (long long)rb->position};
+        const int64_t pushed = steps * env->N;
+        if (rb->position + pushed >= rb->capacity) rb->full = true;  // :85-86
+        rb->position = (rb->position + pushed) % rb->capacity;
+    }
     const bool persistent = persistent_path(e, env, learn);
     if (learn && e->opt_path == 2 && !persistent)
         return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and action_size <= 64 (have %lld agents, %d actions)",
@@ -581,7 +603,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         const int FLAG_ACCOUNT_X = FLAG_ACCOUNT | (getenv("QE_DEBUG_FLAGS") ? atoi(getenv("QE_DEBUG_FLAGS")) << 20 : 0);
 #define FLAG_ACCOUNT FLAG_ACCOUNT_X
 #endif
-        const bool lean = mode == QE_LEARN_ITER && !c.trace;
+        const bool lean = mode == QE_LEARN_ITER && !c.trace && !c.rp.s;
         auto go = [&](auto nv, auto masked) {
             constexpr int NV = decltype(nv)::value;
             constexpr bool MK = decltype(masked)::value;
@@ -723,6 +745,7 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
                     (double)(sl.hb->cyc1 - sl.hb->cyc0) / ((double)(sl.hb->clk1 - sl.hb->clk0) / e->wall_clock_khz * 1e3),
                     clock_ms * 1e3, (long long)sl.steps);
         if (sl.timed) HIP_TRY(hipEventSynchronize(sl.ev1));
+        if (e->replay) HIP_TRY(hipStreamSynchronize(e->stream));  // ring entries are read through other streams
         // the environment's state after this rollout sits in the block (unless the next rollout of a
         // pipelined call is already moving it on)
         const RolloutSlot& other = e->slots[&sl == &e->slots[0] ? 1 : 0];
@@ -954,6 +977,7 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
 
 int qe_destroy(qe_engine* e) {
     if (!e) return QE_OK;
+    if (e->replay) e->replay->attached = nullptr;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->q) (void)hipFree(e->q);
@@ -1592,17 +1616,6 @@ int qe_delta_apply_sorted_dev(qe_engine* e, const void* dev_entries, int64_t cou
 }
 
 // ---- experience replay ring ---------------------------------------------------------------------
-struct qe_replay {
-    int device = 0;
-    int64_t capacity = 0, position = 0;
-    bool full = false;
-    DevBuf<int64_t> s, a, n, idx, o_s, o_a, o_n;
-    DevBuf<double> r, o_r;
-    DevBuf<uint8_t> d, o_d;
-    DevBuf<unsigned> bad;
-    hipStream_t stream = nullptr;
-};
-
 int qe_replay_create(qe_replay** out, int32_t device, int64_t capacity) {
     if (!out || capacity <= 0) return fail(QE_ERR_INVALID, "capacity must be > 0");
     *out = nullptr;
@@ -1627,6 +1640,7 @@ int qe_replay_create(qe_replay** out, int32_t device, int64_t capacity) {
 
 int qe_replay_destroy(qe_replay* rb) {
     if (!rb) return QE_OK;
+    if (rb->attached) rb->attached->replay = nullptr;
     (void)hipSetDevice(rb->device);
     if (rb->stream) { (void)hipStreamSynchronize(rb->stream); (void)hipStreamDestroy(rb->stream); }
     rb->s.release(); rb->a.release(); rb->n.release(); rb->r.release(); rb->d.release(); rb->idx.release();
@@ -1660,6 +1674,19 @@ int qe_replay_push(qe_replay* rb, const int64_t* states, const int64_t* actions,
         done_n += piece;
     }
     HIP_TRY(hipStreamSynchronize(rb->stream));  // the host arrays are borrowed for the call only
+    return QE_OK;
+}
+
+int qe_replay_attach(qe_engine* e, qe_replay* rb) {
+    if (!e) return fail(QE_ERR_INVALID, "engine is NULL");
+    if (rb && rb->device != e->device) return fail(QE_ERR_INVALID, "replay buffer and engine live on different devices");
+    if (e->slots[0].busy || e->slots[1].busy) return fail(QE_ERR_INVALID, "a rollout is in flight");
+    if (e->replay) e->replay->attached = nullptr;
+    if (rb) {
+        if (rb->attached && rb->attached != e) rb->attached->replay = nullptr;
+        rb->attached = e;
+    }
+    e->replay = rb;
     return QE_OK;
 }
 

@@ -16,8 +16,8 @@
 //   wide mode (>= 2048 agents): k_token_round x R between the two works most involved agents off on
 //                    the whole chip (lowest pending toucher of every row goes first), k_advance runs
 //                    the selections that had to wait for them; k_compact / *_list walk compacted lists.
-//   k_rollout_persistent: <= 512 agents -- the whole loop in ONE launch on one CU, contention
-//                    tracked in LDS, one workgroup barrier per quiet step.
+//   k_rollout_lane (qe_rollout_lane.h): <= 512 agents, <= 64 actions -- the whole loop in ONE launch on one
+//                    CU, one agent per lane, contention tracked in LDS, one workgroup barrier per quiet step.
 //
 // Why that is exact: a row touched by a single agent in step t holds the same values at every
 // point of the reference's step t, so reading it once (after step t-1 completed: kernel boundary)
@@ -63,6 +63,18 @@ struct Ctrl {
 struct DeltaEntry {
     uint32_t cell;
     float delta;
+};
+
+// Experience-replay ring attached to the fused rollout (algorithms/buffers/experience_replay.py:68-86:
+// every transition is pushed, here device to device): entry of agent i at vector step t goes to slot
+// (pos0 + t * N + i) mod cap -- the order in which a host loop would push them.
+struct ReplayDev {
+    int64_t* s;   // nullptr: no ring attached
+    int64_t* a;
+    int64_t* n;
+    double* r;
+    uint8_t* d;
+    long long cap, pos0;
 };
 
 // Result block of one rollout in page-locked, host-coherent memory.  The LAST kernel of a rollout
@@ -127,6 +139,7 @@ struct Ctx {
     int32_t* trace;
     DeltaEntry* dlog;
     long long dlog_base, dlog_cap;
+    ReplayDev rp;
     // host result block (persistent kernel; nullptr: results stay in device memory)
     HostBlock* hb;
     int32_t* hb_obs;
@@ -197,6 +210,15 @@ __device__ __forceinline__ void account(const Ctx<T>& c, long long t, int64_t i,
 }
 
 template <typename T>
+__device__ __forceinline__ void replay_put(const Ctx<T>& c, long long t, int64_t i, int32_t s, int32_t a, float r,
+                                           int32_t n, bool term) {
+    if (c.rp.s) {
+        const long long slot = (c.rp.pos0 + t * c.N + i) % c.rp.cap;
+        c.rp.s[slot] = s; c.rp.a[slot] = a; c.rp.r[slot] = (double)r; c.rp.n[slot] = n; c.rp.d[slot] = term ? 1 : 0;
+    }
+}
+
+template <typename T>
 __device__ __forceinline__ void log_delta(const Ctx<T>& c, long long t, int64_t i, int64_t cell, T u) {
     if (c.dlog) {
         const long long slot = c.dlog_base + t * c.N + i;
@@ -239,6 +261,7 @@ __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx
             if (tr.next_obs != n) touch(c.stamps, tr.next_obs, par1, TOUCH_R);
         }
         if (c.trace) c.trace[t1 * c.N + i] = act;
+        replay_put(c, t1, i, n, act, tr.reward, tr.next_obs, tr.terminated);
     }
     p.s = n; p.a = act; p.pred = picked; p.r = tr.reward; p.term = tr.terminated; p.n = tr.next_obs;
 }
@@ -905,444 +928,10 @@ __global__ __launch_bounds__(SLOW_BLOCK) void k_step_slow(Ctx<T> c, EnvCtx ev, i
 }
 
 // -------------------------------------------------------------------------------------------------
-// Persistent rollout: when all agents fit one workgroup (<= 512 agents, <= 1024 lanes) the whole
-// `steps`-step loop runs in ONE launch on one CU.
-//   * agent state and the pending transition stay in registers across steps;
-//   * the step boundary is ONE workgroup barrier in a quiet step (no kernel boundary);
-//   * row contention is tracked in three rotating LDS hash tables (row -> writers<<16 | readers,
-//     lowest toucher index) instead of the global stamps: no global atomics on the critical path
-//     (measured on MI355X: a global atomic + completion wait 0.4-0.7 us, an LDS atomic ~0.05 us);
-//   * the row gather is issued right after the barrier and the Philox draws of the next selection
-//     are computed while it is in flight;
-//   * the episode log is staged in LDS and flushed in bulk (this workgroup owns ctrl->ep_count);
-//   * the lane-group width is a template parameter, so reductions lower to DPP moves.
-// Shared rows: on every contested row the lowest-indexed toucher proceeds at once (its inputs
-// cannot have been modified yet), the others run afterwards in index order -- in place, in short
-// barrier-separated rounds, when every contested row has exactly two touchers (the common case),
-// through slow_body otherwise.  An agent whose next-state row is written by another agent in this
-// step re-reads that row after all updates before selecting its next action.
-constexpr int PERSIST_MAX_LANES = 1024;
-constexpr int PERSIST_MAX_AGENTS = 512;
-constexpr int CT_SLOTS = 2048;      // contention table slots (>= 2 x touches per step)
+// Persistent rollout (<= 512 agents, <= 64 actions): the whole `steps`-step loop in ONE launch on one CU,
+// one agent per lane -- qe_rollout_lane.h.  Constants shared with it:
 constexpr int EP_STAGE = 1024;      // staged episode-log entries
 constexpr int PERSIST_CACHE_BYTES = 16 * 1024;  // LDS row cache of the ordered path
-
-struct PersistLds {
-    SlowLdsT<PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES> slow;
-    int ct_key[3][CT_SLOTS];
-    unsigned ct_cnt[3][CT_SLOTS];
-    int ct_min[3][CT_SLOTS];
-    unsigned long long ep_key[EP_STAGE];
-    float ep_ret[EP_STAGE];
-    unsigned char pending[PERSIST_MAX_AGENTS];  // 1 while an agent's deferred update is outstanding
-    alignas(16) unsigned char cold[384];  // the launch context, for the rare paths (see the kernel)
-    unsigned def_bits[PERSIST_MAX_AGENTS / 32];  // deferred agents of a step (general ordered path), by index
-    unsigned busy[3];     // step t: some row has more than one toucher
-    unsigned ep_n;
-    unsigned n_def;       // agents whose update is deferred in this step
-    unsigned n_rem;       // ... and not yet executed
-    unsigned complex_;    // a contested row has more than two touchers
-};
-
-__device__ __forceinline__ int ct_insert(PersistLds& l, int tb, int32_t row, unsigned kind, int agent) {
-    int h = (int)(mix32((uint32_t)row) & (CT_SLOTS - 1));
-    for (;;) {
-        const int old = atomicCAS(&l.ct_key[tb][h], -1, row);
-        if (old == -1 || old == row) break;
-        h = (h + 1) & (CT_SLOTS - 1);
-    }
-    if (atomicAdd(&l.ct_cnt[tb][h], kind) != 0u) l.busy[tb] = 1u;
-    atomicMin(&l.ct_min[tb][h], agent);
-    return h;
-}
-
-#ifdef QE_STAMPS
-#define QE_STAMP(k) do { const long long _n = wall_clock64(); stamp_sum[k] += _n - stamp_last; stamp_last = _n; } while (0)
-#else
-#define QE_STAMP(k) do { } while (0)
-#endif
-
-// LEAN = the launch is known to be a plain training rollout (sequential `learn`, no action trace, no
-// delta log): the compiler is told so, which removes three families of uniform branches and their
-// operands from the scalar-register budget of the loop.
-template <typename T, class Env, int LC, int BLOCK = 1024, int LEAN = 0>
-__global__ __launch_bounds__(BLOCK) void k_rollout_persistent(InlineSched /*at offset 0 of the kernarg segment*/,
-                                                              Ctx<T> c, EnvCtx ev, long long steps, int flags) {
-    __shared__ PersistLds lds;
-    const unsigned long long clk0 = wall_clock64();
-    if (c.thr == nullptr) {  // short rollout: the schedule values came with the launch
-        const QE_AS4 unsigned char* ka = (const QE_AS4 unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
-        c.thr = (const QE_AS4 unsigned long long*)ka;
-        c.lr = (const QE_AS4 double*)(ka + sizeof(unsigned long long) * INLINE_SCHED_STEPS);
-    }
-    if constexpr (LEAN != 0) { c.mode = 0; c.trace = nullptr; }
-    if constexpr (LEAN == 1) c.dlog = nullptr;
-#ifdef QE_STAMPS
-    long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long stamp_last = wall_clock64();
-    if (threadIdx.x == 0) for (int k = 8; k < 24; ++k) c.vinc[k] = 0.0;
-#endif
-    const int tid = threadIdx.x;
-    const int L = LC ? LC : c.L;
-    const int i = tid >> c.lshift;
-    const int sub = tid & (L - 1);
-    const bool active = i < c.N;
-    const int ii = active ? i : 0;
-    const bool lead = active && sub == 0;
-    const int sflags = flags | FLAG_NO_STAMPS;
-    Pending<T> p;
-    p.n = c.n[ii];
-    p.aux = c.aux[ii];
-    p.s = 0; p.a = 0; p.pred = 0; p.r = 0.0f; p.term = false;
-    float acc = c.acc[ii];
-    unsigned long long deferred_total = 0, ep_base = 0;
-    U4 batch{0u, 0u, 0u, 0u};  // Philox blocks of the next steps, one per lane of the group
-    // table slots of steps t-1 / t-2.  Lane 0 of a group owns the row-s slot; the row-n slot is owned
-    // by lane 1 (slot) when the group has two or more lanes, by lane 0 (slot2) otherwise.
-    int cur_slot = -1, prev_slot = -1, cur_slot2 = -1, prev_slot2 = -1;
-    const int flush_every = 32;  // steps per flush window of the staged episode log
-    int flush_in = flush_every;
-    for (int k = tid; k < 3 * CT_SLOTS; k += (int)blockDim.x) {
-        (&lds.ct_key[0][0])[k] = -1;
-        (&lds.ct_cnt[0][0])[k] = 0u;
-        (&lds.ct_min[0][0])[k] = 0x7FFFFFFF;
-    }
-    for (int k = tid; k < PERSIST_MAX_AGENTS; k += (int)blockDim.x) lds.pending[k] = 0;
-    if (tid < PERSIST_MAX_AGENTS / 32) lds.def_bits[tid] = 0u;
-    // The context is ~70 scalar registers; what only the rare paths need (agent arrays for the general
-    // ordered path, log pointers for the periodic flush, the epilogue) is parked in LDS and fetched
-    // when such a path runs, so that the quiet step does not pay for scalar-register spills.
-    static_assert(sizeof(Ctx<T>) <= sizeof(lds.cold), "context stash too small");
-    if (tid == 0) {
-        *reinterpret_cast<Ctx<T>*>(lds.cold) = c;
-        lds.ep_n = 0u; lds.n_def = 0u; lds.n_rem = 0u; lds.complex_ = 0u;
-        lds.busy[0] = lds.busy[1] = lds.busy[2] = 0u;
-        c.ctrl->error = 0u;  // this launch owns the control block: no host-side memset in front of it
-        c.ctrl->inv_count = 0u;
-    }
-    __syncthreads();  // the control block is initialised before any wave may report through it
-    {   // select(0), env.step(0)
-        const Row4<T> row = load_row4(c.q, p.n, c.ld, sub);
-        if (active) advance_regs<T, Env, LC>(c, ev, i, sub, row, Env::valid4(ev, i, p.n, sub), 0, sflags, p);
-    }
-    __syncthreads();
-    int tb = 0;  // t % 3
-    DeltaEntry* dl = c.dlog ? c.dlog + c.dlog_base + ii : nullptr;  // this agent's record of step 0
-    const long long dl_steps = c.dlog ? (c.dlog_cap - c.dlog_base) / c.N : 0;  // steps whose records all fit
-    for (long long t = 0; t < steps; ++t) {
-        const bool last = t + 1 == steps;
-        const bool dl_ok = t < dl_steps;
-        const int tb_old = tb == 2 ? 0 : tb + 1;  // (t - 2) % 3 == (t + 1) % 3: retired two barriers ago
-        QE_STAMP(7);
-        // ---- register this step's touches (W(s), R(n)); retire the entries of step t-2 ---------
-        // lane 0 of the group handles row s, lane 1 (when the group has one) row n: the two chains of
-        // dependent LDS atomics run side by side.
-        const bool two = LC != 1 && L > 1;
-        {
-            const bool mine = active && (sub == 0 || (two && sub == 1));
-            if (mine) {
-                const bool second = two ? sub == 1 : false;  // this lane's job: row n (else row s)
-                // before the rotation `prev_slot` is my slot of step t-2, which lives in table tb_old
-                if (prev_slot >= 0) {
-                    lds.ct_key[tb_old][prev_slot] = -1; lds.ct_cnt[tb_old][prev_slot] = 0u;
-                    lds.ct_min[tb_old][prev_slot] = 0x7FFFFFFF;
-                }
-                if (!two && prev_slot2 >= 0) {
-                    lds.ct_key[tb_old][prev_slot2] = -1; lds.ct_cnt[tb_old][prev_slot2] = 0u;
-                    lds.ct_min[tb_old][prev_slot2] = 0x7FFFFFFF;
-                }
-                prev_slot = cur_slot; prev_slot2 = cur_slot2;
-                const bool skip = second && p.n == p.s;
-                cur_slot = skip ? -1 : ct_insert(lds, tb, second ? p.n : p.s, second ? 1u : 1u << 16, i);
-                cur_slot2 = (!two && p.n != p.s) ? ct_insert(lds, tb, p.n, 1u, i) : -1;
-            }
-        }
-        if (tid == 0) lds.busy[tb_old] = 0u;
-        QE_STAMP(0);
-        __syncthreads();  // every table write of step t-1 is complete; touches of step t are in
-        QE_STAMP(1);
-        const bool busy = lds.busy[tb] != 0u;
-        Row4<T> row = load_row4(c.q, p.n, c.ld, sub);  // the one row gather of a quiet step
-        const uint32_t valid = Env::valid4(ev, ii, p.n, sub);
-        // ---- classification (only when some row has several touchers) ---------------------------
-        int cls = 3;  // bit0: update now, bit1: select now
-        int pred_s = -1, pred_n = -1;
-        if (busy) {
-            // row-n facts live on lane 1 of the group (lane 0 when the group is a single lane)
-            unsigned cn = 0u;
-            int mn = 0x7FFFFFFF, has_n = 0;
-            {
-                const int ns = two ? cur_slot : cur_slot2;
-                if (active && (two ? sub == 1 : sub == 0) && ns >= 0) {
-                    cn = lds.ct_cnt[tb][ns]; mn = lds.ct_min[tb][ns]; has_n = 1;
-                }
-            }
-            if (two) {
-                cn = group_bcast<LC, 1>(cn, L); mn = group_bcast<LC, 1>(mn, L); has_n = group_bcast<LC, 1>(has_n, L);
-            }
-            if (lead) {
-                const unsigned cs = lds.ct_cnt[tb][cur_slot];
-                const int ms = lds.ct_min[tb][cur_slot];
-                const unsigned w_s = cs >> 16, tot_s = w_s + (cs & 0xFFFFu);
-                const unsigned w_n = cn >> 16, tot_n = w_n + (cn & 0xFFFFu);
-                bool now = true, sel = true, cx = false;
-                if (c.mode == 1) {
-                    // VEC (learn_vec): every toucher of a row that is written AND shared reads the
-                    // pre-step table, so all of them go through the batch path together
-                    const bool shared = w_s >= 2u || (w_s == 1u && tot_s >= 2u) || (has_n && w_n >= 1u && tot_n >= 2u);
-                    if (shared) { now = false; cx = true; }
-                    sel = !(has_n ? w_n > 0u : w_s > 1u);
-                } else {
-                    if (tot_s > 1u && ms < i) { now = false; pred_s = ms; cx |= tot_s > 2u; }
-                    if (has_n) {
-                        if (w_n > 0u) {
-                            sel = false;  // someone writes the row my next action is chosen from
-                            if (!p.term && mn < i) { now = false; pred_n = mn; cx |= tot_n > 2u; }
-                        }
-                    } else if (w_s > 1u) {
-                        sel = false;  // n == s and another agent writes this row too
-                    }
-                }
-                cls = (now ? 1 : 0) | (sel ? 2 : 0);
-                if (!now) {
-                    lds.pending[i] = 1;
-                    atomicAdd(&lds.n_def, 1u);
-                    if (cx) lds.complex_ = 1u;
-                }
-            }
-            if (LC != 1) cls = group_bcast<LC, 0>(cls, L);
-        }
-        QE_STAMP(2);
-        // ---- Philox draws of select(t+1): independent of memory, computed under the row gather.
-        // A group of LB lanes serves one agent, so every LB-th step each lane evaluates the block of a
-        // DIFFERENT upcoming step (lane k: step t+1+k); the other steps just fetch their block from the
-        // lane that holds it.  One Philox evaluation per LB steps instead of one per step.
-        constexpr int LB = LC >= 4 ? 4 : (LC == 2 ? 2 : 1);
-        U4 x;
-        if (LB == 1) {
-            const unsigned long long step1 = c.step0 + (unsigned long long)(t + 1);
-            x = philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)step1, (uint32_t)(step1 >> 32),
-                              STREAM_POLICY, c.seed_lo, c.seed_hi);
-        } else {
-            const int phase = (int)(t & (LB - 1));
-            if (phase == 0) {
-                const unsigned long long stepk = c.step0 + (unsigned long long)(t + 1) + (unsigned)(sub & (LB - 1));
-                batch = philox4x32_10(c.agent_offset + (uint32_t)ii, (uint32_t)stepk, (uint32_t)(stepk >> 32),
-                                      STREAM_POLICY, c.seed_lo, c.seed_hi);
-            }
-            // `phase` is uniform, so the block is fetched from its lane with a DPP broadcast chosen by a
-            // scalar branch (LB lanes = one quad or half a quad)
-            auto fetch = [&](auto k) {
-                constexpr int K = decltype(k)::value;
-                x.x = group_bcast<LB, K>(batch.x, LB); x.y = group_bcast<LB, K>(batch.y, LB);
-                x.z = group_bcast<LB, K>(batch.z, LB);
-            };
-            if (phase == 0) fetch(std::integral_constant<int, 0>{});
-            else if (phase == 1) fetch(std::integral_constant<int, 1>{});
-            else if (phase == 2) fetch(std::integral_constant<int, LB == 4 ? 2 : 0>{});
-            else fetch(std::integral_constant<int, LB == 4 ? 3 : 1>{});
-            x.w = 0u;
-        }
-        const float r_t = p.r;
-        const bool term_t = p.term;
-        QE_STAMP(3);
-        // ---- update of transition t for agents that may go now ----------------------------------
-        if (active && (cls & 1)) {
-            const T m = row_max_valid<LC>(row, valid, L);
-            const int64_t cell = (int64_t)p.s * c.ld + p.a;
-            T u;
-            const T q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, c.lr[t]), c.mode, &u);
-            if (sub == 0) {
-                c.q[cell] = q1;
-                // delta log of the replica exchange: a running pointer instead of log_delta's 64-bit
-                // slot arithmetic (slot = base + t * N + agent)
-                if (dl_ok) *dl = DeltaEntry{(uint32_t)cell, (float)u};
-            }
-            if (p.n == p.s && (p.a >> 2) == sub) {
-                const int j = p.a & 3;
-                if (j == 0) row.v[0] = q1; else if (j == 1) row.v[1] = q1;
-                else if (j == 2) row.v[2] = q1; else row.v[3] = q1;
-            }
-        }
-        if (active) {  // base_runtime.py:212,218-221 for transition t
-            acc += r_t;
-            if (term_t) {
-                if (sub == 0 && (flags & FLAG_ACCOUNT)) {
-                    // entry k of this flush window lands at log position ep_base + k: through the LDS
-                    // stage normally, straight to memory when more episodes end in one window than
-                    // the stage holds (never happens at the usual termination rates)
-                    const unsigned k = atomicAdd(&lds.ep_n, 1u);
-                    const unsigned long long key = ((unsigned long long)t << 32) | (unsigned long long)i;
-                    if (k < (unsigned)EP_STAGE) {
-                        lds.ep_key[k] = key;
-                        lds.ep_ret[k] = acc;
-                    } else {
-                        const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
-                        if ((long long)(ep_base + k) < cc.ep_cap) {
-                            cc.ep_key[ep_base + k] = key;
-                            cc.ep_ret[ep_base + k] = acc;
-                        }
-                    }
-                }
-                acc = 0.0f;
-            }
-        }
-        QE_STAMP(4);
-        if (active && cls == 3 && !last) {
-            advance_with_draws<T, Env, LC>(c, ev, i, sub, row, valid, t + 1, sflags, x, p);
-        }
-        QE_STAMP(5);
-
-        if (busy) {
-            // ---- extended step: ordered updates of the deferred agents, then late selections -----
-#ifdef QE_STAMPS
-            const long long ext_t0 = wall_clock64();
-#endif
-            __syncthreads();
-            const int n_def = (int)lds.n_def;
-#ifdef QE_STAMPS
-            if (tid == 0) { c.vinc[16] += 1.0; if (n_def > 0) c.vinc[17] += 1.0; }
-#endif
-            if (n_def > 0) {
-                deferred_total += (unsigned long long)n_def;
-                if (lds.complex_) {
-                    // general case: hand the deferred transitions to slow_body through the arrays
-                    // hot fields from the kernel arguments, the parked ones from LDS; the step-wise
-                    // kernels' contention structures do not exist in this kernel
-                    const Ctx<T>& cold = *reinterpret_cast<const Ctx<T>*>(lds.cold);
-                    Ctx<T> cc = c;
-                    cc.s = cold.s; cc.a = cold.a; cc.n = cold.n; cc.r = cold.r; cc.term = cold.term;
-                    cc.pred = cold.pred; cc.aux = cold.aux; cc.acc = cold.acc;
-                    cc.inv_bitmap = cold.inv_bitmap; cc.inv_list = cold.inv_list; cc.vinc = cold.vinc;
-                    cc.ctrl = cold.ctrl; cc.ep_key = cold.ep_key; cc.ep_ret = cold.ep_ret; cc.ep_cap = cold.ep_cap;
-                    cc.stamps = nullptr; cc.tok = nullptr; cc.adv_bitmap = nullptr; cc.pend_list = nullptr;
-                    const bool mine_def = lead && !(cls & 1);
-                    if (c.mode == 0) {
-                        // Sequential learn: the deferred transitions go from their owners' registers
-                        // straight into the ordered path's LDS staging area, at the owner's rank among the
-                        // deferred agents (the ordered path works on an index-sorted list); nothing goes
-                        // through the agent arrays in memory.
-                        if (mine_def) atomicOr(&lds.def_bits[i >> 5], 1u << (i & 31));
-                        barrier_lds();
-                        if (mine_def) {
-                            int pos = __popc(lds.def_bits[i >> 5] & ((1u << (i & 31)) - 1u));
-                            for (int w = 0; w < (i >> 5); ++w) pos += __popc(lds.def_bits[w]);
-                            lds.slow.a_agent[pos] = i; lds.slow.a_s[pos] = p.s; lds.slow.a_a[pos] = p.a;
-                            lds.slow.a_n[pos] = p.n; lds.slow.a_r[pos] = p.r; lds.slow.a_term[pos] = p.term ? 1 : 0;
-                            lds.pending[i] = 0;
-                        }
-                        barrier_lds();
-                        if (tid < PERSIST_MAX_AGENTS / 32) lds.def_bits[tid] = 0u;
-                        slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES, LC>(
-                            cc, ev, FLAG_NO_STAMPS | FLAG_LEARN | FLAG_PRESTAGED, t, n_def, lds.slow);
-                    } else {
-                        if (mine_def) {
-                            cc.s[i] = p.s; cc.a[i] = p.a; cc.pred[i] = p.pred; cc.r[i] = p.r;
-                            cc.term[i] = p.term ? 1 : 0; cc.n[i] = p.n; cc.aux[i] = p.aux;
-                            atomicOr(&cc.inv_bitmap[i >> 5], 1u << (i & 31));
-                            lds.pending[i] = 0;
-                        }
-                        __syncthreads();
-                        (void)build_involved_list(cc, lds.slow.scan);  // == n_def agents
-                        slow_body<T, Env, PERSIST_MAX_AGENTS, PERSIST_CACHE_BYTES, LC>(cc, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
-                    }
-                    __syncthreads();
-                } else {
-                    // lds.n_def itself counts down (every wave has copied it into `n_def` above)
-                    bool mine = active && !(cls & 1);
-                    if (LC != 1) { pred_s = group_bcast<LC, 0>(pred_s, L); pred_n = group_bcast<LC, 0>(pred_n, L); }
-                    int rounds = 0;
-                    while (lds.n_def > 0u && rounds++ <= n_def) {
-#ifdef QE_STAMPS
-                        if (tid == 0) c.vinc[18] += 1.0;
-#endif
-                        const bool go = mine && (pred_s < 0 || lds.pending[pred_s] == 0) &&
-                                        (pred_n < 0 || lds.pending[pred_n] == 0);
-                        barrier_lds();  // everyone has sampled the flags of this round
-                        if (go) {
-                            T m = 0;
-                            if (!p.term) {
-                                const Row4<T> fresh = load_row4(c.q, p.n, c.ld, sub);
-                                m = row_max_valid<LC>(fresh, valid, L);
-                            }
-                            if (sub == 0) {
-                                const int64_t cell = (int64_t)p.s * c.ld + p.a;
-                                const T q0 = c.q[cell];
-                                T u;
-                                c.q[cell] = Td<T>::apply(q0, p.r, m, p.term, make_hyper(c, c.lr[t]), 0, &u);
-                                log_delta(c, t, i, cell, u);
-                                lds.pending[i] = 0;
-                                atomicSub(&lds.n_def, 1u);
-                            }
-                            mine = false;
-                        }
-                        __syncthreads();  // this round's table writes are complete and visible
-                    }
-                    if (tid == 0 && lds.n_def > 0u) reinterpret_cast<const Ctx<T>*>(lds.cold)->ctrl->error = 2u;
-                }
-            }
-            // every update of step t is in the table: late selections read their row again
-            if (active && cls != 3 && !last) {
-                const Row4<T> fresh = load_row4(c.q, p.n, c.ld, sub);
-                advance_with_draws<T, Env, LC>(c, ev, i, sub, fresh, valid, t + 1, sflags, x, p);
-            }
-            if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }
-#ifdef QE_STAMPS
-            if (tid == 0) c.vinc[19] += (double)(wall_clock64() - ext_t0);
-#endif
-        }
-        // ---- bulk flush of the staged episode log (uniform, data-independent decision) ----------
-        if (--flush_in == 0 || last) {
-            flush_in = flush_every;
-            __syncthreads();
-            const unsigned staged = lds.ep_n;
-            const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
-            unsigned long long* const out_key = cc.ep_key;
-            float* const out_ret = cc.ep_ret;
-            const long long out_cap = cc.ep_cap;
-            for (unsigned k = tid; k < min(staged, (unsigned)EP_STAGE); k += blockDim.x) {
-                const unsigned long long pos = ep_base + k;
-                if ((long long)pos < out_cap) { out_key[pos] = lds.ep_key[k]; out_ret[pos] = lds.ep_ret[k]; }
-            }
-            ep_base += staged;
-            __syncthreads();
-            if (tid == 0) lds.ep_n = 0u;
-        }
-        tb = tb == 2 ? 0 : tb + 1;
-        if (c.dlog) dl += c.N;
-        QE_STAMP(6);
-    }
-#ifdef QE_STAMPS
-    if (tid == 0 && c.vinc) for (int k = 0; k < 8; ++k) c.vinc[k] = (double)stamp_sum[k];
-#endif
-    const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
-    if (lead) {
-        cc.n[i] = p.n; cc.aux[i] = p.aux; cc.acc[i] = acc;
-        if (cc.hb) { cc.hb_obs[i] = p.n; cc.hb_aux[i] = p.aux; cc.hb_acc[i] = acc; }
-    }
-    if (tid == 0) {
-        cc.ctrl->involved_total = deferred_total;
-        cc.ctrl->ep_count = ep_base;
-        cc.ctrl->t_local = steps;
-    }
-    if (cc.hb) {
-        // Publish to the host: every wave's stores to the pinned arrays have left the GPU (vmcnt),
-        // then one lane writes the block and, last, the sequence number the host is spinning on.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            HostBlock* hb = cc.hb;
-            hb->ep_count = ep_base;
-            hb->involved_total = deferred_total;
-            hb->error = cc.ctrl->error;
-            hb->clk0 = clk0;
-            hb->clk1 = wall_clock64();
-            __threadfence_system();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&hb->seq, cc.hb_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
 
 // -------------------------------------------------------------------------------------------------
 // Wide mode (many agents): the involved agents of a step are first worked off by token rounds that

@@ -1,20 +1,18 @@
 // qe_rollout_lane.h -- persistent rollout, ONE AGENT PER LANE (gfx950, wave64).
 //
 // The whole `steps`-step training loop of up to 512 agents (rows of up to 64 actions) in one launch on
-// one CU, like k_rollout_persistent (qe_kernels.h), but every lane owns a whole agent: its Q-row
-// (4*NV values from NV 16-byte loads) sits in the lane's registers, arg-max / tie count / k-th tie /
-// picked value are computed in-lane with no cross-lane traffic at all.  128 agents are then TWO
-// wavefronts (one per SIMD) instead of eight: a quarter of the vector issue, no DPP chains, and a
-// workgroup barrier between two waves instead of eight (measured on the 128-agent headline shape with
-// the 4-lanes-per-row kernel: select + env.step 0.71 us, barrier wait 0.44 us, LDS touch inserts 0.35 us
-// of a 2.5 us step).
+// one CU.  Every lane owns a whole agent: its Q-row (4*NV values from NV 16-byte loads) sits in the lane's
+// registers; arg-max / tie count / k-th tie / picked value are computed in-lane with no cross-lane traffic
+// at all.  128 agents are TWO wavefronts (one per SIMD); round 1's kernel spread a row over four lanes
+// (eight wavefronts) and spent, of a 2.5 us step, 0.71 us in select + env.step (DPP chains), 0.44 us
+// waiting at the barrier between eight waves and 0.35 us in LDS touch inserts.
 //
-// Exactness is inherited from the step structure of k_rollout_persistent, unchanged:
-//   * touches of step t (W(row s), R(row n)) go into one of three rotating LDS hash tables before the
-//     step's barrier; a slot is ONE 64-bit word {row + 1, writers, readers}, so the usual case -- first
-//     toucher of the row -- is a single compare-and-swap round trip;
-//   * quiet step (no row with two touchers): row gather -> TD update of Q[s,a] -> selection of the next
-//     action from the same registers (own write patched in) -> env.step;
+// Exactness: a row touched by one agent in a step holds the same values at every point
+// of the reference's sequential step, so that agent may run concurrently with everyone else and reuse its
+// one row gather for the TD target of step t and the selection of step t+1; rows that are written AND
+// shared are ordered:
+//   * quiet step (no written row with a second toucher): row gather -> TD update of Q[s,a] -> selection of
+//     the next action from the same registers (own write patched in) -> env.step;
 //   * busy step: on every contested row the lowest-indexed toucher proceeds at once, the others follow in
 //     index order -- in place when every contested row has two touchers, through slow_body (the ordered
 //     path of qe_kernels.h, which brings its own lane-group view of the rows) otherwise; an agent whose
@@ -204,7 +202,7 @@ struct LaneLds {
     unsigned long long ep_key[EP_STAGE];
     float ep_ret[EP_STAGE];
     unsigned char pending[CAP];   // 1 while an agent's deferred update is outstanding
-    alignas(16) unsigned char cold[384];  // the launch context, for the rare paths
+    alignas(16) unsigned char cold[448];  // the launch context, for the rare paths
     unsigned def_bits[CAP / 32];  // deferred agents of a step (general ordered path), by index
     unsigned busy[5];             // step k (mod 4): some written row has a second toucher; [4] = dump
     unsigned ep_n;
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         c.thr = (const QE_AS4 unsigned long long*)ka;
         c.lr = (const QE_AS4 double*)(ka + sizeof(unsigned long long) * INLINE_SCHED_STEPS);
     }
-    if constexpr (LEAN != 0) { c.mode = 0; c.trace = nullptr; }
+    if constexpr (LEAN != 0) { c.mode = 0; c.trace = nullptr; c.rp.s = nullptr; }
     if constexpr (LEAN == 1) c.dlog = nullptr;
 #ifdef QE_STAMPS
     long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -310,6 +308,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         const int32_t n = p.n;
         const Transition tr = Env::step(ev, i, n, p.aux, act, c.step0 + (unsigned long long)t1);
         if (c.trace) c.trace[t1 * c.N + i] = act;
+        replay_put(c, t1, i, n, act, tr.reward, tr.next_obs, tr.terminated);
         p.s = n; p.a = act; p.pred = picked; p.r = tr.reward; p.term = tr.terminated; p.n = tr.next_obs;
     };
     auto philox_of = [&](long long t1) {

@@ -233,6 +233,11 @@ int qe_replay_create(qe_replay** out, int32_t device, int64_t capacity);
 int qe_replay_destroy(qe_replay* rb);
 int qe_replay_push(qe_replay* rb, const int64_t* states, const int64_t* actions, const double* rewards,
                    const int64_t* next_states, const uint8_t* done, int64_t n);
+/* Wire the ring to the fused rollout: from now on every transition (s, a, r, s', done) of every agent and
+ * vector step of qe_rollout / qe_rollout_begin / qe_rollout_fused on this engine is pushed device to device,
+ * in (step, agent) order -- what a host loop calling push after every env.step would store (:68-86);
+ * position / full advance accordingly.  rb == NULL detaches. */
+int qe_replay_attach(qe_engine* e, qe_replay* rb);
 int64_t qe_replay_len(qe_replay* rb);
 int64_t qe_replay_position(qe_replay* rb);
 int32_t qe_replay_full(qe_replay* rb);

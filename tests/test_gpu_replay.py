@@ -83,3 +83,57 @@ def test_replay_errors():
     rb.push((99, 0, 0.0, 1, False))  # a state the table below does not have
     with pytest.raises(IndexError):
         rb.learn_from(Algo(10, 3, 0.9, seed=0), 2, 0.1)
+
+
+@pytest.mark.parametrize(("n", "S", "A", "steps", "capacity", "path"), [
+    (96, 500, 8, 25, 96 * 25 + 17, "auto"),      # persistent kernel, everything fits the ring
+    (96, 500, 8, 40, 1000, "auto"),              # ... and wrapping around it
+    (600, 3000, 16, 12, 600 * 12, "stepwise"),   # step-wise kernels
+])
+def test_fused_rollout_pushes_every_transition_into_the_ring(n, S, A, steps, capacity, path):
+    """experience_replay.py:68-86 wired to the fused loop: the ring holds (s, a, r, s', done) of every agent and
+    vector step in (step, agent) order -- what a host loop pushing after every env.step would store."""
+    from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
+    from dist_classicrl_amd.environments import HashTabularEnv
+    from dist_classicrl_amd.schedules import ConstantSchedule
+    from oracle.envs import HashTabularEnv as OracleEnv
+
+    Replay, Algo = _classes()
+    algo = Algo(S, A, 0.99, seed=0)
+    algo.set_rollout_path(path)
+    rb = Replay(capacity, 1)
+    rb.attach(algo)
+    rt = GpuRolloutQLearning(algo, ConstantSchedule(0.1), ConstantSchedule(0.3))
+    rt.trace_actions = True
+    try:
+        rt.run_steps(steps, HashTabularEnv(n, S, A, seed=1), None)
+    except ZeroDivisionError:
+        pass
+    actions = rt.last_trace
+    # the same environment driven by those actions on the CPU
+    env = OracleEnv(n, S, A, seed=1)
+    obs, _ = env.reset()
+    want = []
+    for t in range(steps):
+        nxt, r, term, _, _ = env.step(actions[t])
+        want.append((obs.copy(), actions[t].copy(), r.copy(), nxt.copy(), term.copy()))
+        obs = nxt
+    ws, wa, wr, wn, wd = (np.concatenate([w[k] for w in want]) for k in range(5))
+    total = steps * n
+    assert (rb.position, rb.full, len(rb)) == (total % capacity, total >= capacity, min(total, capacity))
+    slots = np.arange(total) % capacity
+    live = np.arange(total) >= total - capacity  # later pushes overwrite earlier ones
+    gs, ga, gr, gn, gd = rb.state_buffer, rb.action_buffer, rb.reward_buffer, rb.next_state_buffer, rb.done_buffer
+    assert np.array_equal(gs[slots[live]], ws[live]) and np.array_equal(ga[slots[live]], wa[live])
+    assert np.array_equal(gr[slots[live]], wr[live].astype(np.float64)) and np.array_equal(gn[slots[live]], wn[live])
+    assert np.array_equal(gd[slots[live]], wd[live].astype(bool))
+    before = np.asarray(algo.q_table).copy()
+    rb.learn_from(algo, 64, 0.1)  # the optional replay phase: sample -> learn without leaving the device
+    assert not np.array_equal(before, np.asarray(algo.q_table))
+    rb.detach(algo)
+    pos = rb.position
+    try:
+        rt.run_steps(3, HashTabularEnv(n, S, A, seed=1), None)
+    except ZeroDivisionError:
+        pass
+    assert rb.position == pos  # detached: nothing is pushed any more
