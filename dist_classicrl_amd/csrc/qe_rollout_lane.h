@@ -292,6 +292,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         c.ctrl->inv_count = 0u;
     }
     __syncthreads();  // tables and control block are initialised
+    if ((QX(6) && worker) || (QX(7) && helper)) return;  // (timing experiments)
 
     // selection + env.step of step t1 from `row` (= Q[p.n]); the new pending transition replaces p
     auto advance = [&](const RowV<T, NV>& row, M valid, long long t1, const U4& x, unsigned long long thr_t1) {
@@ -390,15 +391,20 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
     // sit in front of the update / the selection of every step)
     double lr_t = c.lr[0];
     unsigned long long thr_t1 = c.thr[steps > 1 ? 1 : 0];
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     for (long long t = 0; t < steps; ++t) {
         const bool last = t + 1 == steps;
         const bool dl_ok = t < dl_steps;
-        const double lr_next = c.lr[last ? t : t + 1];
-        const unsigned long long thr_next = c.thr[t + 2 < steps ? t + 2 : steps - 1];
+        // (vector loads through a laundered zero offset: as scalar loads the compiler waits for each of them
+        // on the spot -- two scalar-memory round trips in front of every step; a vector load is simply in
+        // flight until the values are used, at the end of the step)
+        const double lr_next = ((const double*)(uintptr_t)c.lr)[(last ? t : t + 1) + vzero];
+        const unsigned long long thr_next = ((const unsigned long long*)(uintptr_t)c.thr)[(t + 2 < steps ? t + 2 : steps - 1) + vzero];
         QL_STAMP(7);
         const bool busy = lds.busy[t & 3] != 0u;
         const U4 x = draws(t + 1);
-        if (helper && !last) produce(t + 2);
+        if (helper && !last && !QX(5)) produce(t + 2);
         if (stale) load_row_lane<NV>(row, c.q, p.n);
         const M valid = valid_mask_lane<Env, NV, MASKED>(ev, ii, p.n);
         QL_STAMP(0);
@@ -483,26 +489,19 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
                 for (int j = 0; j < 4 * NV; ++j) row.v[j] = j == p.a ? q1 : row.v[j];
             }
         }
-        if (active) {  // base_runtime.py:212,218-221 for transition t
+        // base_runtime.py:212,218-221 for transition t.  An episode that ends is staged in LDS (flushed in
+        // bulk): ONE returning LDS atomic per wavefront reserves the slots of all its lanes, and its result
+        // is only consumed at the end of the step (ep_store below), so no LDS round trip sits here.
+        unsigned ep_raw = 0;       // what the reserving lane's atomic returned (consumed at the end of the step)
+        unsigned long long enders = 0;
+        float ep_value = 0.0f;
+        if (active) {
             acc += r_t;
+            enders = __ballot(term_t && (flags & FLAG_ACCOUNT));
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(enders >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)enders, 0u));
             if (term_t) {
-                if (flags & FLAG_ACCOUNT) {
-                    // entry k of this flush window lands at log position ep_base + k: through the LDS
-                    // stage normally, straight to memory when more episodes end in one window than the
-                    // stage holds
-                    const unsigned k = atomicAdd(&lds.ep_n, 1u);
-                    const unsigned long long key = ((unsigned long long)t << 32) | (unsigned long long)i;
-                    if (k < (unsigned)EP_STAGE) {
-                        lds.ep_key[k] = key;
-                        lds.ep_ret[k] = acc;
-                    } else {
-                        const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
-                        if ((long long)(ep_base + k) < cc.ep_cap) {
-                            cc.ep_key[ep_base + k] = key;
-                            cc.ep_ret[ep_base + k] = acc;
-                        }
-                    }
-                }
+                if (rank == 0) ep_raw = atomicAdd(&lds.ep_n, (unsigned)__popcll(enders));  // the first ending lane
+                ep_value = acc;
                 acc = 0.0f;
             }
         }
@@ -610,6 +609,25 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
 #ifdef QE_STAMPS
             if (tid == 0) c.vinc[19] += (double)(wall_clock64() - ext_t0);
 #endif
+        }
+        if (enders) {  // entry k of this flush window lands at log position ep_base + k
+            const unsigned base = __builtin_amdgcn_readlane(ep_raw, __ffsll((long long)enders) - 1);
+            if ((enders >> (threadIdx.x & 63)) & 1) {
+                const unsigned ep_slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(enders >> 32),
+                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)enders, 0u));
+                const unsigned long long key = ((unsigned long long)t << 32) | (unsigned long long)i;
+                if (ep_slot < (unsigned)EP_STAGE) {
+                    lds.ep_key[ep_slot] = key;
+                    lds.ep_ret[ep_slot] = ep_value;
+                } else {  // more episodes end in one window than the stage holds: straight to memory
+                    asm volatile("" ::: "memory");  // (keeps the loads of the parked context inside this branch)
+                    const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
+                    if ((long long)(ep_base + ep_slot) < cc.ep_cap) {
+                        cc.ep_key[ep_base + ep_slot] = key;
+                        cc.ep_ret[ep_base + ep_slot] = ep_value;
+                    }
+                }
+            }
         }
         // ---- bulk flush of the staged episode log (uniform, data-independent decision) ----------
         if (--flush_in == 0 || last) {
