@@ -253,6 +253,7 @@ def main() -> None:
     for _ in range(ROOFLINE_SAMPLES if persistent else 1):
         sd = run_steps(args.steps, sd)
         samples.append(dict(rt.last_stats))
+    rt.close_training()  # (replicas: the records logged since the last regular exchange, and what is in flight)
     sync_all()
     if rank != 0:
         dist.destroy_process_group()
@@ -360,7 +361,10 @@ def main() -> None:
             line["value"] / PUBLISHED_TICTACTOE_SINGLE_THREAD_128)
     if use_dist:
         line["delta_sync"] = {"syncs": rt.delta_sync.syncs, "bytes_received_per_gpu": rt.delta_sync.bytes_exchanged,
-                              "sync_every": SYNC_EVERY, "collective": "all_gather_into_tensor of (cell, delta) logs"}
+                              "sync_every": SYNC_EVERY, "collective": "all_gather_into_tensor of (cell, delta) logs",
+                              "note": "whole process (warm-up, timed call, roofline samples, final flush); the cadence runs across "
+                                      "calls: a timed call shorter than sync_every steps contains an exchange only if the "
+                                      "100th logged step falls into it"}
     sys.stdout.flush()
     os.dup2(json_fd, 1)
     print(json.dumps(line), flush=True)

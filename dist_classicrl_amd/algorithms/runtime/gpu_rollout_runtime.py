@@ -71,7 +71,8 @@ class GpuRolloutQLearning(BaseRuntime):
         self.learn_mode = learn_mode
         self.last_stats = None  # accumulated qe_rollout_stats of the latest run_steps call
         self.delta_sync = None  # dist_classicrl_amd.distributed.DeltaSync (multi-GPU replicas)
-        self.sync_every = 100
+        self.sync_every = 100   # vector steps between two replica exchanges (BASELINE config 4)
+        self._since_sync = 0    # vector steps logged since the last exchange (the cadence runs across calls)
         # set to True to collect every action of the following run_steps calls (tests); the (steps, n)
         # array of the latest call is left in `last_trace` (and, for older callers, here)
         self.trace_actions = None
@@ -99,7 +100,19 @@ class GpuRolloutQLearning(BaseRuntime):
         return None
 
     def close_training(self) -> None:
-        return None
+        self.flush_replica_exchange()
+
+    def flush_replica_exchange(self) -> None:
+        """Exchange the records logged since the last regular exchange (a training that does not end on a
+        multiple of ``sync_every`` steps) and apply everything still in flight."""
+        sync = self.delta_sync
+        if sync is None:
+            return
+        if self._since_sync:
+            sync.exchange(self._since_sync * sync.capacity // self.sync_every)
+            _lib.check(_lib.load().qe_delta_log_reset(self.algorithm.handle))
+            self._since_sync = 0
+        sync.flush()
 
     def _prepare_env(self, env):
         if isinstance(env, DeviceVecEnv):
@@ -138,39 +151,48 @@ class GpuRolloutQLearning(BaseRuntime):
         history, ep_steps, traces = [], [], []
         chunk_max = max(1, int(lib.qe_rollout_chunk_limit(algo.handle, env.handle, 1 if learn else 0)))
         sync = self.delta_sync if learn else None
-        if sync is not None:
-            chunk_max = min(chunk_max, self.sync_every)
         collect_trace = self.trace_actions is not None and self.trace_actions is not False
         if learn and not collect_trace:
-            # Pipelined: chunk k+1 is enqueued before the results of chunk k are read back, so the GPU
-            # never waits for the host (schedule arithmetic, episode-log handling, replica exchange).
             chunk_max = min(chunk_max, self._PIPELINE_CHUNK)
-            eps = _schedule_values(self.exploration_rate_schedule, n, steps)
-            lr = _schedule_values(self.lr_schedule, n, steps)
-            if steps <= chunk_max:
-                # one launch: the schedule values travel with it (inside the kernel arguments when short)
-                st = _lib.RolloutStats()
-                _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, steps, _f64_ptr(eps), _f64_ptr(lr), mode, 0))
-                try:
-                    if sync is not None:
-                        sync.exchange(steps * n)
-                        _lib.check(lib.qe_delta_log_reset(algo.handle))
-                finally:
-                    rc = lib.qe_rollout_end(algo.handle, 0, C.byref(st))
-                _lib.check(rc)
-                self._collect(lib, algo, st, 0, total, history, ep_steps)
-                if sync is not None:
-                    sync.flush()
-            else:
-                sizes = [min(chunk_max, steps - d) for d in range(0, steps, chunk_max)]
-                starts = np.cumsum([0] + sizes[:-1])
-                # the schedule values of the whole call go to the device once (qe_schedule_plan); the
-                # chunks consume them in order
-                _lib.check(lib.qe_schedule_plan(algo.handle, _f64_ptr(eps), _f64_ptr(lr), steps))
+        # Launches of the call: cut where the episode log could overflow and -- with replicas -- where
+        # `sync_every` steps have been logged since the last exchange (the log keeps filling across calls:
+        # a call shorter than the cadence exchanges nothing, the records wait for the calls that follow).
+        sizes, exchanges, left, since = [], [], steps, self._since_sync if sync is not None else 0
+        while left > 0:
+            k = min(left, chunk_max, self.sync_every - since if sync is not None else left)
+            since += k
+            sizes.append(k)
+            exchanges.append(sync is not None and since == self.sync_every)
+            if exchanges[-1]:
+                since = 0
+            left -= k
+        starts = np.cumsum([0] + sizes[:-1])
+        logged = [self._since_sync if sync is not None else 0]  # steps in the current log, by chunk
+
+        def exchange(k):
+            logged[0] += sizes[k]
+            if exchanges[k]:  # all-gather of the (cell, delta) records since the last exchange, stream-ordered
+                sync.exchange(logged[0] * n)
+                _lib.check(lib.qe_delta_log_reset(algo.handle))
+                logged[0] = 0
+
+        try:
+            if learn and not collect_trace:
+                # Pipelined: chunk k+1 is enqueued before the results of chunk k are read back, so the GPU
+                # never waits for the host (schedule arithmetic, episode-log handling, replica exchange).
+                eps = _schedule_values(self.exploration_rate_schedule, n, steps)
+                lr = _schedule_values(self.lr_schedule, n, steps)
+                one = len(sizes) == 1
+                if not one:
+                    # the schedule values of the whole call go to the device once (qe_schedule_plan); the
+                    # chunks consume them in order.  (One launch: they travel with it, inside the kernel
+                    # arguments when short.)
+                    _lib.check(lib.qe_schedule_plan(algo.handle, _f64_ptr(eps), _f64_ptr(lr), steps))
                 begun = []  # chunks enqueued and not yet collected
 
                 def begin(k):
-                    _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, sizes[k], None, None, mode, k & 1))
+                    _lib.check(lib.qe_rollout_begin(algo.handle, env.handle, sizes[k], _f64_ptr(eps) if one else None,
+                                                    _f64_ptr(lr) if one else None, mode, k & 1))
                     begun.append(k)
 
                 def end(k):
@@ -178,11 +200,6 @@ class GpuRolloutQLearning(BaseRuntime):
                     begun.remove(k)
                     _lib.check(lib.qe_rollout_end(algo.handle, k & 1, C.byref(st)))
                     self._collect(lib, algo, st, int(starts[k]), total, history, ep_steps)
-
-                def exchange(k):
-                    if sync is not None:  # all-gather of chunk k's (cell, delta) records, stream-ordered
-                        sync.exchange(sizes[k] * n)
-                        _lib.check(lib.qe_delta_log_reset(algo.handle))
 
                 try:
                     begin(0)
@@ -195,35 +212,29 @@ class GpuRolloutQLearning(BaseRuntime):
                 finally:
                     # an exception (e.g. the reference's IndexError for an agent without a selectable
                     # action, or a failed collective) must not leave a slot marked busy: drain what was
-                    # begun, ignoring its status, and complete the exchange in flight
+                    # begun, ignoring its status
                     for k in list(begun):
                         lib.qe_rollout_end(algo.handle, k & 1, None)
                     begun.clear()
-                    if sync is not None:
-                        sync.flush()  # remote deltas still in flight are applied before returning
-        else:
-            done = 0
-            try:
-                while done < steps:
-                    k = min(chunk_max, steps - done)
+            else:
+                for k, size in enumerate(sizes):
                     st = _lib.RolloutStats()
                     if learn:
-                        eps = _schedule_values(self.exploration_rate_schedule, n, k)
-                        lr = _schedule_values(self.lr_schedule, n, k)
-                        trace = np.empty((k, n), dtype=np.int32)
-                        _lib.check(lib.qe_rollout(algo.handle, env.handle, k, _f64_ptr(eps), _f64_ptr(lr), mode,
+                        eps = _schedule_values(self.exploration_rate_schedule, n, size)
+                        lr = _schedule_values(self.lr_schedule, n, size)
+                        trace = np.empty((size, n), dtype=np.int32)
+                        _lib.check(lib.qe_rollout(algo.handle, env.handle, size, _f64_ptr(eps), _f64_ptr(lr), mode,
                                                   _lib.ptr(trace, C.c_int32), C.byref(st)))
                         traces.append(trace)
-                        if sync is not None:
-                            sync.exchange(k * n)
-                            _lib.check(lib.qe_delta_log_reset(algo.handle))
+                        exchange(k)
                     else:
-                        _lib.check(lib.qe_evaluate(algo.handle, env.handle, k, C.byref(st)))
-                    self._collect(lib, algo, st, done, total, history, ep_steps)
-                    done += k
-            finally:
-                if sync is not None:
-                    sync.flush()
+                        _lib.check(lib.qe_evaluate(algo.handle, env.handle, size, C.byref(st)))
+                    self._collect(lib, algo, st, int(starts[k]), total, history, ep_steps)
+        finally:
+            if sync is not None:
+                self._since_sync = logged[0]
+                if any(exchanges):
+                    sync.flush()  # the exchange still in flight is completed (remote deltas applied) before returning
         self.last_stats = total
         if traces:
             self.last_trace = np.concatenate(traces)

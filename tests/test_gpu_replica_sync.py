@@ -43,6 +43,11 @@ def test_one_rank_exchange_equals_plain_run(n, S, A, steps, sync_every):
             rt.sync_every = sync_every
             rt.delta_sync = attach_engine(algo, sync_every, n)
         _, history, _, sd = rt.run_steps(steps, HashTabularEnv(n, S, A, seed=5), None)
+        if with_sync:
+            # the cadence runs across calls: a regular exchange every sync_every steps; the records logged
+            # after the last one go out when the training is closed
+            assert rt.delta_sync.syncs == steps // sync_every
+            rt.close_training()
         syncs = rt.delta_sync.syncs if with_sync else 0
         return np.asarray(algo.q_table), np.array(history), sd["states"], syncs
 
