@@ -94,10 +94,11 @@ class OptimalQLearningBase:
     def set_rollout_path(self, path: str) -> None:
         """Tuning knob, never changes results: ``"auto"``, ``"stepwise"`` (one kernel pair per vector
         step), ``"persistent"`` (one launch per rollout; needs <= 512 agents and agents x lanes-per-row
-        <= 1024) or ``"wide"`` (step-wise, the ordered path spread over the whole chip; automatic
-        from 2048 agents, both learn modes)."""
+        <= 1024), ``"wide"`` (step-wise, the ordered path spread over the whole chip) or ``"turnstile"``
+        (one launch per vector step, shared rows handed from agent to agent inside it: ``learn_iter``
+        with up to ~60 000 agents; elsewhere the automatic choice applies)."""
         code = {"auto": _lib.PATH_AUTO, "stepwise": _lib.PATH_STEPWISE, "persistent": _lib.PATH_PERSISTENT,
-                "wide": _lib.PATH_WIDE}[path]
+                "wide": _lib.PATH_WIDE, "turnstile": _lib.PATH_TURNSTILE}[path]
         _lib.check(self._lib.qe_set_option(self._h, _lib.OPT_ROLLOUT_PATH, code))
 
     def set_engine_option(self, option: int, value: int) -> None:

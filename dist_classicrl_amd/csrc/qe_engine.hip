@@ -16,6 +16,7 @@
 
 #include "qe_kernels.h"
 #include "qe_rollout_lane.h"
+#include "qe_step_turn.h"
 
 using namespace qe;
 
@@ -151,7 +152,7 @@ struct RolloutSlot {
     PinnedBuf<Ctrl> h_ctrl;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, sched_ready = nullptr;
     std::vector<hipEvent_t> sample_ev;  // event pairs around sampled dominant-kernel launches
-    bool busy = false, persistent = false, wide = false, timed = true;
+    bool busy = false, persistent = false, wide = false, turn = false, timed = true;
     int n_samples = 0;
     int64_t steps = 0, N = 0, launches = 0;
     int32_t* trace_host = nullptr;
@@ -207,7 +208,11 @@ struct qe_engine {
     uint64_t seed = 0, step_ctr = 0;
     double wall_clock_khz = 100000.0;  // rate of wall_clock64() (s_memrealtime), ticks per millisecond
     uint32_t agent_offset = 0;
+    int num_cus = 64;
     int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
+    unsigned long long turn_epoch = 1;  // turnstile path: list tag of the next call's step 0 (0 = the touch counters' rest value)
+    bool stamps_hold_lists = false;     // the touch-counter array holds turnstile list heads (cleared before counters use it)
+    int turn_blocks_per_cu = 0;         // resident workgroups per CU the turnstile kernels are dispatched for (0: not yet queried)
     int opt_graph = 1; // QE_OPT_USE_GRAPH
     int opt_rounds = 0; // QE_OPT_TOKEN_ROUNDS (0 = automatic)
     int auto_rounds = 4; // wide mode: rounds chosen from the previous call's statistics
@@ -277,6 +282,7 @@ struct qe_env {
     DevBuf<float> r, acc;
     DevBuf<uint8_t> term, pred, masks;
     DevBuf<uint32_t> aux, bitmap, adv_bitmap;
+    DevBuf<uint32_t> turn_next, turn_prog;  // turnstile path: [2][N][2] each, allocated on first use
     DevBuf<double> vinc;
     // host copy of (observations, env-internal state, running returns) left by the latest rollout's
     // result block; valid until anything else changes the device state
@@ -385,17 +391,57 @@ static int slot_host_block(qe_engine* e, RolloutSlot& sl, size_t agents) {
     return QE_OK;
 }
 
+// Turnstile path (qe_step_turn.h): its workgroups wait for each other inside the launch, so all of them
+// must be resident -- FAST_BLOCK threads each, TURN_BLOCKS_PER_CU per CU asked for (the kernels need
+// <= 128 registers: four workgroups of four wavefronts fit a CU) -- and the progress counts are 16 bits.
+constexpr int TURN_BLOCKS_PER_CU = 2;
+constexpr bool TURN_AUTO = true;  // automatic choice for agent counts above the persistent kernel's
+static bool turn_fits(const qe_engine* e, int64_t N) {
+    const int64_t blocks = (N * e->L + FAST_BLOCK - 1) / FAST_BLOCK;
+    return N <= 60000 && blocks <= (int64_t)e->num_cus * TURN_BLOCKS_PER_CU && e->ld <= 256;
+}
+// The touch-counter array doubles as the turnstile path's list heads; the counters' kernels expect zeros.
+static int stamps_as_counters(qe_engine* e) {
+    if (e->stamps_hold_lists) {
+        HIP_TRY(hipMemsetAsync(e->stamps, 0, (size_t)e->S * 2 * sizeof(unsigned long long), e->stream));
+        e->stamps_hold_lists = false;
+    }
+    return QE_OK;
+}
+
 // one launch per rollout on one CU, one agent per lane with its whole row in registers (qe_rollout_lane.h)
 static bool persistent_path(const qe_engine* e, const qe_env* env, int learn) {
     return learn && env->N <= LANE_MAX_AGENTS && e->ld <= 64 && (e->opt_path == 0 || e->opt_path == 2);
 }
 
+// Room for a schedule plan of `count` steps (page-locked staging + device copy): sized generously and doubled
+// when outgrown, re-allocating pinned memory costs milliseconds.  No rollout may be in flight.
+static int plan_reserve(qe_engine* e, size_t count) {
+    size_t cap = std::max<size_t>(e->plan_thr.cap, (size_t)1 << 16);
+    while (cap < count) cap *= 2;
+    if (cap > e->h_plan_thr.cap) {
+        HIP_TRY(e->h_plan_thr.ensure(cap)); HIP_TRY(e->h_plan_lr.ensure(cap));
+        if (int rc = warm_pinned(e, e->h_plan_thr.p, e->h_plan_thr.cap * 8)) return rc;
+        if (int rc = warm_pinned(e, e->h_plan_lr.p, e->h_plan_lr.cap * 8)) return rc;
+    }
+    if (cap > e->plan_thr.cap) {
+        HIP_TRY(e->plan_thr.ensure(cap)); HIP_TRY(e->plan_lr.ensure(cap));
+        // ... and the exact pair qe_schedule_plan uses, over the whole new capacity
+        HIP_TRY(hipMemcpyAsync(e->plan_thr.p, e->h_plan_thr.p, cap * 8, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(hipMemcpyAsync(e->plan_lr.p, e->h_plan_lr.p, cap * 8, hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    }
+    return QE_OK;
+}
+
 int slot_prepare(qe_engine* e, RolloutSlot& sl, int64_t steps, const double* eps, const double* lr, bool use_plan,
                  bool persistent) {
-    // both result slots are set up at the first rollout: a later, longer call that pipelines through the
-    // second slot does not pay for allocations then
+    // both result slots and the schedule plan's buffers are set up at the first rollout: a later, longer
+    // call that pipelines through the second slot does not pay for allocations then
     for (RolloutSlot& each : e->slots)
         if (int rc = slot_create(e, each)) return rc;
+    if (!e->plan_thr.cap && !e->slots[0].busy && !e->slots[1].busy)
+        if (int rc = plan_reserve(e, 0)) return rc;
     sl.plan_offset = -1;
     sl.inline_sched = false;
     if (use_plan) {  // the values are already on the device
@@ -443,6 +489,12 @@ void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& e
                  int sample = -1) {
     const dim3 grid(grid_for(c.N * c.L, FAST_BLOCK)), block(FAST_BLOCK);
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample], e->stream);
+    if (c.turn_next) {  // turnstile path: the whole vector step is this one launch (qe_step_turn.h)
+        hipLaunchKernelGGL((k_step_turn<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags | FLAG_TURN);
+        if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
+        ++sl.launches;
+        return;
+    }
     hipLaunchKernelGGL((k_step_fast<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags);
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
     ++sl.launches;
@@ -560,9 +612,23 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     if (learn && e->opt_path == 2 && !persistent)
         return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and action_size <= 64 (have %lld agents, %d actions)",
                     (long long)env->N, (int)e->A);
+    // turnstile path: one launch per step, all workgroups resident, rows handed from agent to agent
+    const bool turn = learn && !persistent && mode == QE_LEARN_ITER && turn_fits(e, env->N) &&
+                      (e->opt_path == 4 || (e->opt_path == 0 && TURN_AUTO));
+    if (turn) {
+        const size_t words = (size_t)env->N * 4;
+        HIP_TRY(env->turn_next.ensure(words));
+        HIP_TRY(env->turn_prog.ensure(words));
+        c.turn_next = env->turn_next.p; c.turn_prog = env->turn_prog.p;
+        c.turn_epoch = e->turn_epoch;
+        e->turn_epoch += (unsigned long long)steps + 2ull;  // tags of this call: epoch .. epoch + steps
+        e->stamps_hold_lists = true;
+    } else if (learn && !persistent) {
+        if (int rc = stamps_as_counters(e)) return rc;
+    }
     // wide mode: exact sequential updates, many agents, ordered path spread over the chip
-    const bool wide = learn && !persistent &&
-                      (e->opt_path == 3 || (e->opt_path == 0 && env->N >= 2048));
+    const bool wide = learn && !persistent && !turn &&
+                      (e->opt_path == 3 || ((e->opt_path == 0 || e->opt_path == 4) && env->N >= 2048));
     if (wide) {
         if (!e->tok) {
             HIP_TRY(hipMalloc((void**)&e->tok, (size_t)e->S * 2 * sizeof(uint32_t)));
@@ -575,7 +641,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         if (env->N >= e->listed_min && sl.rounds >= LISTED_MIN_ROUNDS) c.pend_list = env->pend_list.p;
     }
     sl.launches = 0; sl.n_samples = 0; sl.steps = steps; sl.N = env->N; sl.persistent = persistent;
-    sl.wide = wide;
+    sl.wide = wide; sl.turn = turn;
     sl.trace_host = trace_host;
     sl.dbg = env->vinc.p;
     sl.env = env;
@@ -584,7 +650,9 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     // trace still has to be copied out of device memory, which needs the end-of-kernel event anyway.
     sl.fast = persistent && e->opt_host_block && !trace_host;
     if (sl.fast) {
-        if (int rc = slot_host_block(e, sl, (size_t)env->N)) return rc;
+        // (both slots' blocks at once: a later, longer call that pipelines through the other slot finds it ready)
+        for (RolloutSlot& each : e->slots)
+            if (int rc = slot_host_block(e, each, (size_t)env->N)) return rc;
         sl.seq = ++e->seq_ctr;
         c.hb = sl.hb; c.hb_obs = sl.hb_obs; c.hb_aux = sl.hb_aux; c.hb_acc = sl.hb_acc; c.hb_seq = sl.seq;
         c.ep_key = sl.hb_key; c.ep_ret = sl.hb_ret; c.ep_cap = HOST_LOG_CAP;
@@ -917,6 +985,9 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
         int khz = 0;
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0)
             e->wall_clock_khz = (double)khz;
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            e->num_cus = cus;
     }
     e->device = device; e->dtype = dtype; e->S = S; e->A = A; e->ld = row_stride(A);
     e->L = lanes_per_row(e->ld);
@@ -1006,7 +1077,7 @@ int qe_synchronize(qe_engine* e) {
 }
 
 int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
-    if (option == QE_OPT_ROLLOUT_PATH && value >= 0 && value <= 3) { e->opt_path = (int)value; return QE_OK; }
+    if (option == QE_OPT_ROLLOUT_PATH && value >= 0 && value <= 4) { e->opt_path = (int)value; return QE_OK; }
     if (option == QE_OPT_USE_GRAPH && (value == 0 || value == 1)) { e->opt_graph = (int)value; return QE_OK; }
     if (option == QE_OPT_LISTED_MIN_AGENTS && value >= 1) { e->listed_min = value; return QE_OK; }
     if (option == QE_OPT_TOKEN_ROUNDS && value >= 0 && value <= MAX_TOKEN_ROUNDS) { e->opt_rounds = (int)value; return QE_OK; }
@@ -1225,6 +1296,7 @@ static int learn_launch(qe_engine* e, int64_t n, double lr, bool masked, int32_t
             hipLaunchKernelGGL(k_learn_large<T>, dim3(1), dim3(64), 0, e->stream, c, ev, lr);
             return;
         }
+        (void)stamps_as_counters(e);
         hipLaunchKernelGGL(k_touch_batch<T>, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, c);
         const int flags = FLAG_LEARN | FLAG_PRED_FROM_TABLE;
         hipLaunchKernelGGL((k_step_fast<T, HostEnv>), dim3(grid_for(n * e->L, FAST_BLOCK)), dim3(FAST_BLOCK), 0, e->stream, c, ev, flags);
@@ -1327,7 +1399,7 @@ int qe_env_destroy(qe_env* env) {
     (void)hipStreamSynchronize(env->e->stream);
     env->s.release(); env->a.release(); env->n.release(); env->list.release(); env->pend_list.release(); env->r.release();
     env->acc.release(); env->term.release(); env->pred.release(); env->aux.release();
-    env->bitmap.release(); env->adv_bitmap.release(); env->masks.release(); env->vinc.release();
+    env->bitmap.release(); env->adv_bitmap.release(); env->turn_next.release(); env->turn_prog.release(); env->masks.release(); env->vinc.release();
     delete env;
     return QE_OK;
 }
@@ -1471,21 +1543,7 @@ int qe_schedule_plan(qe_engine* e, const double* eps, const double* lr, int64_t 
     // the compute stream at this point was measured at 7 ms.)
     e->plan_count = 0; e->plan_cursor = 0;
     if (count == 0) return QE_OK;
-    // sized generously and doubled when outgrown: re-allocating pinned memory costs milliseconds
-    size_t cap = std::max<size_t>(e->plan_thr.cap, (size_t)1 << 16);
-    while (cap < (size_t)count) cap *= 2;
-    if (cap > e->h_plan_thr.cap) {
-        HIP_TRY(e->h_plan_thr.ensure(cap)); HIP_TRY(e->h_plan_lr.ensure(cap));
-        if (int rc = warm_pinned(e, e->h_plan_thr.p, e->h_plan_thr.cap * 8)) return rc;
-        if (int rc = warm_pinned(e, e->h_plan_lr.p, e->h_plan_lr.cap * 8)) return rc;
-    }
-    if (cap > e->plan_thr.cap) {
-        HIP_TRY(e->plan_thr.ensure(cap)); HIP_TRY(e->plan_lr.ensure(cap));
-        // ... and the exact pair used below, over the whole new capacity
-        HIP_TRY(hipMemcpyAsync(e->plan_thr.p, e->h_plan_thr.p, cap * 8, hipMemcpyHostToDevice, e->copy_stream));
-        HIP_TRY(hipMemcpyAsync(e->plan_lr.p, e->h_plan_lr.p, cap * 8, hipMemcpyHostToDevice, e->copy_stream));
-        HIP_TRY(hipStreamSynchronize(e->copy_stream));
-    }
+    if (int rc = plan_reserve(e, (size_t)count)) return rc;
     for (int64_t t = 0; t < count; ++t) e->h_plan_thr.p[t] = eps_threshold(eps[t]);
     memcpy(e->h_plan_lr.p, lr, (size_t)count * sizeof(double));
     if (!e->plan_ready) HIP_TRY(hipEventCreateWithFlags(&e->plan_ready, hipEventDisableTiming));

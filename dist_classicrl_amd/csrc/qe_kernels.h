@@ -46,6 +46,7 @@ constexpr int FLAG_T_MINUS_1 = 64;       // the step counter has already been ad
 constexpr int FLAG_LIST_IN_LDS = 512;    // ordered path: the involved list (<= CAP entries) is mirrored in its LDS a_agent[]
 constexpr int FLAG_PRESTAGED = 256;      // ordered path: the caller has staged the transitions in LDS (persistent kernel)
 constexpr int FLAG_VEC_INC_READY = 128;  // VEC, wide mode: the increments of the involved agents are already in vinc
+constexpr int FLAG_TURN = 1024;           // turnstile path: touches are registered on per-row lists (qe_step_turn.h)
 constexpr uint32_t TOK_INF = 0xFFFFFFFFu;
 constexpr unsigned ERR_EMPTY_CHOICE = 3u;  // Ctrl::error: a fused selection found no selectable action
 
@@ -58,6 +59,7 @@ struct Ctrl {
     unsigned long long involved_total;   // statistics: agents that reached the ordered path
     unsigned long long pending_total;    // statistics (wide mode, listed rounds): agents that entered the token rounds
     unsigned int pend_count[2];          // entries of the two pending lists of the current step
+    unsigned int blocks_done;            // turnstile path: workgroups of the current launch that have finished
 };
 
 struct DeltaEntry {
@@ -112,6 +114,10 @@ struct Ctx {
     uint32_t* tok;          // [2][S] lowest pending agent per row (wide mode; nullptr otherwise)
     uint32_t* adv_bitmap;   // agents whose selection of step t+1 waits for all updates of step t
     int32_t* pend_list;     // N: agents that entered the token rounds of this step (wide mode at large N)
+    // turnstile path (qe_step_turn.h; nullptr otherwise): `stamps` holds the list heads
+    uint32_t* turn_next;    // [2][N][2] next node of the row list an agent is on (per parity and role)
+    uint32_t* turn_prog;    // [2][N][2] progress word of the row whose lowest toucher the agent is
+    unsigned long long turn_epoch;  // tag of step 0 of this call (tags never repeat in an engine's life)
     Ctrl* ctrl;
     // agent state: pending transition (s, a, pred, r, term) and current observation n
     int32_t* s;
@@ -238,6 +244,9 @@ struct Pending {
     uint32_t aux;
 };
 
+template <typename T>
+__device__ __forceinline__ void turn_push(const Ctx<T>& c, int64_t i, int64_t row, int role, long long t1);
+
 template <typename T, class Env, int LC = 0>
 __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
                                                    const Row4<T>& row, uint32_t valid, long long t1,
@@ -255,7 +264,10 @@ __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx
     const int32_t n = p.n;
     const Transition tr = Env::step(ev, i, n, p.aux, act, c.step0 + (unsigned long long)t1);
     if (sub == 0) {
-        if (!(flags & FLAG_NO_STAMPS)) {
+        if (flags & FLAG_TURN) {
+            turn_push(c, i, n, 1, t1);
+            if (tr.next_obs != n) turn_push(c, i, tr.next_obs, 0, t1);
+        } else if (!(flags & FLAG_NO_STAMPS)) {
             const int par1 = (int)(t1 & 1);
             touch(c.stamps, n, par1, TOUCH_W);
             if (tr.next_obs != n) touch(c.stamps, tr.next_obs, par1, TOUCH_R);

@@ -1,0 +1,267 @@
+// One launch per vector step for 513 ... ~60 000 agents ("turnstile" path).
+//
+// The step-wise / wide paths order the agents that share a Q-row with further launches (token rounds, the
+// one-workgroup clean-up, the postponed selections): 5-6 dependent kernels per step, 36 us at 4096 agents.
+// Here the whole step is ONE launch whose workgroups are all resident, and the few agents that share a
+// row pass it on to each other inside the launch:
+//
+// * registration (in the PREVIOUS launch, when the transition is selected): each agent pushes itself
+//   on a linked list per touched row -- `head[row][parity]` (the touch-counter array of the other
+//   paths, same layout) is exchanged for {step tag, agent, role}, the old head becomes the agent's
+//   `next`.  A head with another step's tag is an empty list: nothing is ever cleared.
+// * at the start of the launch the lists are complete (kernel boundary).  An agent walks the list of
+//   the row it writes (role W) and of the row it reads (role R, next observation): K touchers, how
+//   many of them / how many writers among them have a lower agent index, and the lowest toucher,
+//   whose per-agent slot holds the row's progress word {writers done << 16 | readers done}.
+//   Alone on its rows (or only readers share them): the plain path of k_step_fast.
+// * otherwise the reference's sequential order over agents (`learn_iter`,
+//   q_learning_optimal.py:770-817) is the order along every row: a WRITER proceeds when all lower
+//   touchers of its row are done, a READER when all lower writers are done (readers between two writers
+//   run side by side); it then updates with coherent accesses and advances the progress words of both
+//   rows.  Waits only ever point to lower agent indices, so the lowest waiting agent always runs.
+//   The selection of step t+1 (which reads the row after ALL updates of step t) waits for all
+//   writers of its row.
+// * table accesses of contested agents and the progress words are device-scope read-modify-write
+//   atomics (they execute at the memory side, the per-XCD L2s are not coherent with each other;
+//   a plain or sc1 load may be served from an L2 line fetched before a remote update).  Uncontested
+//   agents never touch a contested row inside the launch and use plain accesses.
+//
+// Every spin is bounded: after TURN_SPIN_LIMIT polls an agent gives up, raises ERR_TURN_TIMEOUT and all
+// later launches of the rollout return at once -- every wave exits whatever happens.
+#pragma once
+
+namespace qe {
+
+constexpr unsigned ERR_TURN_TIMEOUT = 4u;
+constexpr int TURN_SPIN_LIMIT = 1 << 20;
+constexpr int ROLE_R = 0, ROLE_W = 1;
+
+__device__ __forceinline__ uint32_t opaque_zero() {
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));  // the compiler must not see an idempotent RMW (it would make it a load)
+    return z;
+}
+// value at the coherence point (returning atomic OR with zero)
+__device__ __forceinline__ uint32_t rmw_read(uint32_t* p) {
+    return __hip_atomic_fetch_or(p, opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float rmw_read(float* p) {
+    return __uint_as_float(rmw_read(reinterpret_cast<uint32_t*>(p)));
+}
+__device__ __forceinline__ double rmw_read(double* p) {
+    const unsigned long long z = opaque_zero();
+    return __longlong_as_double((long long)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(p), z,
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// store at the coherence point; the returned old value tells the caller when it has been performed
+__device__ __forceinline__ uint32_t rmw_write(float* p, float v) {
+    return __hip_atomic_exchange(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t rmw_write(double* p, double v) {
+    const unsigned long long o = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p),
+                                                       (unsigned long long)__double_as_longlong(v),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (uint32_t)o ^ (uint32_t)(o >> 32);
+}
+template <typename T>
+__device__ __forceinline__ Row4<T> load_row4_rmw(T* q, int64_t row, int ld, int sub) {
+    Row4<T> r;
+    const int c = 4 * sub;
+    if (c < ld) {
+        T* p = q + row * ld + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.v[j] = rmw_read(p + j);
+    } else {
+        r.v[0] = r.v[1] = r.v[2] = r.v[3] = neg_inf<T>();
+    }
+    return r;
+}
+
+// list head: {tag : 40 | node : 24}, node = ((agent << 1) | role) + 1, 0 = end of list
+__device__ __forceinline__ unsigned long long turn_tag(unsigned long long epoch, long long t) {
+    return (epoch + (unsigned long long)t) & ((1ull << 40) - 1ull);
+}
+__device__ __forceinline__ int64_t turn_slot(int64_t N, int par, int64_t agent, int role) {
+    return (((int64_t)par * N + agent) << 1) | role;
+}
+
+// Registration of agent i as `role` toucher of `row` in step t1 (one lane per agent).
+template <typename T>
+__device__ __forceinline__ void turn_push(const Ctx<T>& c, int64_t i, int64_t row, int role, long long t1) {
+    const int par = (int)(t1 & 1);
+    const unsigned long long tag = turn_tag(c.turn_epoch, t1);
+    const unsigned long long mine = (tag << 24) | (unsigned long long)((((uint32_t)i << 1) | (uint32_t)role) + 1u);
+    const unsigned long long old = atomicExch(&c.stamps[2 * row + par], mine);
+    const int64_t slot = turn_slot(c.N, par, i, role);
+    c.turn_next[slot] = (old >> 24) == tag ? (uint32_t)(old & 0xFFFFFFull) : 0u;
+    c.turn_prog[slot] = 0u;
+}
+
+struct TurnWalk {
+    int K, writers;          // touchers of the row, writers among them
+    int lower, lower_w;      // touchers / writers with a lower agent index than the walker
+    int64_t prog;            // slot of the row's progress word (the lowest toucher's)
+};
+
+// `h` = the row's list head, `own_next` = the walker's own link on this row (loaded early, coalesced)
+template <typename T>
+__device__ __forceinline__ TurnWalk turn_walk(const Ctx<T>& c, unsigned long long h, uint32_t own_next, int par,
+                                              unsigned long long tag, int64_t i) {
+    TurnWalk w{0, 0, 0, 0, 0};
+    uint32_t node = (h >> 24) == tag ? (uint32_t)(h & 0xFFFFFFull) : 0u;
+    int64_t lowest = INT64_MAX;
+    // (a list holds every agent at most once: an agent pushes one node per row)
+    for (int64_t guard = 0; node != 0u && guard <= c.N; ++guard) {
+        const int64_t j = (int64_t)((node - 1u) >> 1);
+        const int role = (int)((node - 1u) & 1u);
+        ++w.K;
+        w.writers += role;
+        if (j < i) { ++w.lower; w.lower_w += role; }
+        if (j < lowest) { lowest = j; w.prog = turn_slot(c.N, par, j, role); }
+        node = j == i ? own_next : c.turn_next[turn_slot(c.N, par, j, role)];
+    }
+    return w;
+}
+
+template <typename T, class Env, int LC = 0>
+__global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, int flags) {
+    const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
+    const int64_t i = gl >> c.lshift;
+    const int sub = (int)(gl & (c.L - 1));
+    const long long t = c.ctrl->t_local;
+    const bool dead = c.ctrl->error == ERR_TURN_TIMEOUT;  // an earlier launch gave up: do nothing
+    if (i < c.N && !dead) {
+        const int32_t n = c.n[i];
+        if (!(flags & FLAG_LEARN)) {  // select(0), env.step(0): registers the touches of step 0
+            Row4<T> row = load_row4(c.q, n, c.ld, sub);
+            advance_agent<T, Env, LC>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t, flags);
+        } else {
+            const int par = (int)(t & 1);
+            const unsigned long long tag = turn_tag(c.turn_epoch, t);
+            const int32_t s = c.s[i];
+            const bool sep = n != s;
+            // everything whose address is known now is requested now (one memory round trip)
+            const uint2 own = *reinterpret_cast<const uint2*>(c.turn_next + turn_slot(c.N, par, i, 0));  // {R, W} links
+            const unsigned long long head_s = c.stamps[2 * (int64_t)s + par];
+            const unsigned long long head_n = c.stamps[2 * (int64_t)n + par];
+            Row4<T> row = load_row4(c.q, n, c.ld, sub);  // valid unless another agent writes row n in this step
+            const int32_t a = c.a[i];
+            const float r = c.r[i];
+            const bool term = c.term[i] != 0;
+            const T pred = c.pred[i];
+            const Hyper hyper = make_hyper(c, c.lr[t]);
+            const uint32_t valid = Env::valid4(ev, i, n, sub);
+            const TurnWalk ws = turn_walk(c, head_s, own.y, par, tag, i);
+            TurnWalk wn{0, 0, 0, 0, 0};
+            if (sep) wn = turn_walk(c, head_n, own.x, par, tag, i);
+            const bool cont_s = ws.K > 1;                        // I write s: any second toucher orders us
+            const bool cont_n = sep && wn.K > 1 && wn.writers > 0;  // readers alone never conflict
+            const int64_t cell = (int64_t)s * c.ld + a;
+            if (!cont_s && !cont_n) {
+                // nobody else touches my rows in this step: k_step_fast's path
+                const T m = row_max_valid<LC>(row, valid, c.L);
+                const T q0 = (flags & FLAG_PRED_FROM_TABLE) ? c.q[cell] : pred;
+                T u;
+                const T q1 = Td<T>::apply(q0, r, m, term, hyper, c.mode, &u);
+                if (sub == 0) {
+                    c.q[cell] = q1;
+                    log_delta(c, t, i, cell, u);
+                    if (flags & FLAG_ACCOUNT) account(c, t, i, r, term);
+                }
+                if (!sep && (a >> 2) == sub) {  // own write lands in the row held in registers
+                    const int j = a & 3;
+                    if (j == 0) row.v[0] = q1; else if (j == 1) row.v[1] = q1;
+                    else if (j == 2) row.v[2] = q1; else row.v[3] = q1;
+                }
+                if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
+            } else {
+                uint32_t* const prog_s = c.turn_prog + ws.prog;
+                uint32_t* const prog_n = c.turn_prog + wn.prog;
+                const int W = LC ? LC : c.L;
+                if (sub == 0) atomicAdd(&c.ctrl->involved_total, 1ull);
+                // the lowest toucher of its rows starts at once
+                const bool wait_s = cont_s && ws.lower > 0, wait_n = cont_n && wn.lower_w > 0;
+                // writers of the row my NEXT action is selected from that come after me in the order
+                const int later_w = sep ? (cont_n ? wn.writers - wn.lower_w : 0) : ws.writers - ws.lower_w - 1;
+                // row n is read coherently where somebody else writes it in this step
+                const bool live_n = sep ? cont_n : true;
+                int phase = 0;
+                for (int spin = 0; phase < 2; ++spin) {
+                    if (spin >= TURN_SPIN_LIMIT) {  // never expected: give up, every later launch returns at once
+                        if (sub == 0) c.ctrl->error = ERR_TURN_TIMEOUT;
+                        break;
+                    }
+                    if (phase == 0) {
+                        int ok = 1;
+                        if (sub == 0) {
+                            if (wait_s) {
+                                const uint32_t d = rmw_read(prog_s);
+                                ok &= (int)((d >> 16) + (d & 0xFFFFu)) == ws.lower;
+                            }
+                            if (wait_n) ok &= (int)(rmw_read(prog_n) >> 16) == wn.lower_w;
+                        }
+                        if (wait_s || wait_n) ok = __shfl(ok, 0, W);
+                        if (ok) {
+                            T q0 = 0;
+                            if (sub == 0) q0 = rmw_read(c.q + cell);  // (pred may predate a lower agent's write)
+                            if (live_n) row = load_row4_rmw(c.q, n, c.ld, sub);
+                            const T m = row_max_valid<LC>(row, valid, c.L);
+                            T u;
+                            const T q1 = Td<T>::apply(q0, r, m, term, hyper, c.mode, &u);
+                            if (sub == 0) {
+                                const uint32_t done = rmw_write(c.q + cell, q1);
+                                log_delta(c, t, i, cell, u);
+                                if (flags & FLAG_ACCOUNT) account(c, t, i, r, term);
+                                // the progress words move only after the exchange has returned (= is performed)
+                                const uint32_t one = 1u | (done & opaque_zero());
+                                if (cont_s) atomicAdd(prog_s, one << 16);
+                                if (cont_n) atomicAdd(prog_n, one);
+                            }
+                            if (later_w == 0) {
+                                // no later writer of the row: what I hold (+ my own write) is the row after step t
+                                if (!sep) {
+                                    const T mine = __shfl(q1, 0, W);
+                                    if ((a >> 2) == sub) {
+                                        const int j = a & 3;
+                                        if (j == 0) row.v[0] = mine; else if (j == 1) row.v[1] = mine;
+                                        else if (j == 2) row.v[2] = mine; else row.v[3] = mine;
+                                    }
+                                }
+                                if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
+                                phase = 2;
+                            } else {
+                                phase = 1;
+                            }
+                        }
+                    }
+                    if (phase == 1) {
+                        // select(t+1) reads Q[n] after every update of step t: all writers of row n done
+                        int ok = 1;
+                        if (sub == 0) ok = (int)(rmw_read(sep ? prog_n : prog_s) >> 16) == (sep ? wn.writers : ws.writers);
+                        ok = __shfl(ok, 0, W);
+                        if (ok) {
+                            if (flags & FLAG_SELECT) {
+                                row = load_row4_rmw(c.q, n, c.ld, sub);
+                                advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
+                            }
+                            phase = 2;
+                        }
+                    }
+                    if (phase < 2) __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+    }
+    // the last workgroup to finish moves the step counter (every workgroup has read it by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(&c.ctrl->blocks_done, 1u);
+        if (prev + 1u == gridDim.x) {
+            c.ctrl->blocks_done = 0u;
+            if ((flags & FLAG_LEARN) && !dead) c.ctrl->t_local = t + 1;
+        }
+    }
+}
+
+}  // namespace qe

@@ -98,7 +98,9 @@ int qe_synchronize(qe_engine* e);
 int qe_set_stream(qe_engine* e, void* hip_stream);
 /* Tuning knobs (never change results).  QE_OPT_ROLLOUT_PATH: 0 = automatic, 1 = one kernel pair per
  * vector step, 2 = persistent single-workgroup kernel (needs num_agents <= 512 and num_agents *
- * lanes_per_row <= 1024), 3 = step-wise with chip-wide token rounds for the ordered path ("wide"). */
+ * lanes_per_row <= 1024), 3 = step-wise with chip-wide token rounds for the ordered path ("wide"),
+ * 4 = one launch per vector step whose resident workgroups hand shared rows from agent to agent
+ * ("turnstile": learn_iter, up to ~60 000 agents; where it does not apply the automatic choice is used). */
 enum qe_option { QE_OPT_ROLLOUT_PATH = 0, QE_OPT_USE_GRAPH = 1 /* 1 (default): replay the step-wise kernels from a HIP graph */,
                  QE_OPT_TOKEN_ROUNDS = 2 /* wide mode: chip-wide rounds per step; 0 (default) = chosen from the previous call */,
                  QE_OPT_LISTED_MIN_AGENTS = 3 /* wide mode: agent count from which the rounds walk compacted lists (default 16384) */,

@@ -225,7 +225,7 @@ def test_learn_vec_many_collisions_stay_exact():
 
 
 # ------------------------------------------------------------------------------- closed loop
-PATHS = ["stepwise", "persistent", "wide", "wide_listed"]
+PATHS = ["stepwise", "persistent", "wide", "wide_listed", "turnstile"]
 
 
 def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="auto"):
@@ -234,6 +234,8 @@ def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="a
     algo = Algo(env.state_size, env.action_size, gamma, seed=seed, dtype=np.dtype(dt))
     if path == "persistent" and (env.action_size > 64 or env.num_agents > 512):
         pytest.skip("more than 512 agents / 64 actions: the persistent kernel does not apply")
+    if path == "turnstile" and mode != "iter":
+        pytest.skip("learn_vec: the turnstile path orders learn_iter only (the engine would take its automatic choice)")
     if path == "wide_listed":  # the compacted-list rounds (automatic from 16384 agents), seven rounds
         from dist_classicrl_amd import _lib
         algo.set_rollout_path("wide")

@@ -2,7 +2,7 @@
 
     python tools/call_overhead.py [steps] [event_timing 0|1] [host_block 0|1]
 """
-import cProfile, io, pstats, sys, time
+import cProfile, io, os, pstats, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from dist_classicrl_amd import _lib
@@ -19,7 +19,7 @@ algo.set_engine_option(_lib.OPT_HOST_BLOCK, host_block)
 env = HashTabularEnv(128, 1_000_000, 16, seed=1)
 rt = GpuRolloutQLearning(algo, ExponentialSchedule(0.1, 1e-5, 0.995), ExponentialSchedule(1.0, 0.01, 0.995))
 _, _, _, sd = rt.run_steps(2000, env, None)
-reps = 300
+reps = int(os.environ.get("REPS", "300"))
 dev = hb = he = 0.0
 t0 = time.perf_counter()
 for _ in range(reps):
