@@ -275,6 +275,18 @@ def main() -> None:
         timing = (f"HIP events on the engine's stream around {launches} further launches of the same {args.steps} steps right "
                   "after the timed region; the timed launch itself carries no events (in-kernel clock: device_region_ms)")
         kernel_note = "one launch runs all K vector steps on one CU: a latency-bound dependent chain per step, not a bandwidth-bound kernel"
+    elif stats["launches"] <= args.steps + 4:
+        # turnstile path (513 .. ~60 000 agents, learn_iter): ONE launch per vector step -- the kernel is the step
+        s0 = samples[0]
+        kernel = "k_step_turn"
+        launches = s0["dominant_launches"]
+        launch_s = s0["dominant_ms"] / max(1, launches) / 1e3
+        units_per_launch = n
+        achieved = bpe * n / launch_s / 1e9 if launch_s > 0 else 0.0
+        timing = (f"HIP events on the engine's stream around each of the first {launches} launches of one further call of the "
+                  "same K steps (the rest of that call is replayed from a HIP graph)")
+        kernel_note = (f"one launch per vector step; whole region of that call: {s0['kernel_ms'] / args.steps * 1e3:.2f} us per step; "
+                       "agents that share a row hand it on inside the launch (latency chain), the others stream")
     else:
         # several kernels per vector step: the roofline figure is the WHOLE step (algorithmic bytes of one
         # vector step / device time of one vector step, HIP events around the region); the engine
