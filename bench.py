@@ -275,7 +275,7 @@ def main() -> None:
         timing = (f"HIP events on the engine's stream around {launches} further launches of the same {args.steps} steps right "
                   "after the timed region; the timed launch itself carries no events (in-kernel clock: device_region_ms)")
         kernel_note = "one launch runs all K vector steps on one CU: a latency-bound dependent chain per step, not a bandwidth-bound kernel"
-    elif stats["launches"] <= args.steps + 4:
+    elif stats["launches"] < 1.5 * args.steps:
         # turnstile path (513 .. ~60 000 agents, learn_iter): ONE launch per vector step -- the kernel is the step
         s0 = samples[0]
         kernel = "k_step_turn"

@@ -15,7 +15,7 @@ def one(pattern):
     hits = glob.glob(str(src / pattern), recursive=True)
     if not hits:
         raise SystemExit(f"missing {pattern}")
-    return hits[0]
+    return max(hits, key=lambda h: Path(h).stat().st_mtime)  # gpurun_out/ accumulates earlier collections
 
 
 def bench_line(log):
@@ -25,7 +25,9 @@ def bench_line(log):
     raise SystemExit(f"no bench line in {log}")
 
 
-for wl in ("headline", "c3", "c5", "wide"):
+for wl in ("headline", "c3", "c5", "c4shard", "wide"):
+    if wl == "c4shard" and not glob.glob(str(src / "c4shard_stats.log")):
+        continue
     shutil.copy(one(f"{wl}_stats/**/*kernel_stats.csv"), dst / f"{tag}_{wl}_kernel_stats.csv")
     json.dump(bench_line(src / f"{wl}_stats.log"), open(dst / f"{tag}_{wl}_bench_under_rocprof.json", "w"), indent=1)
 
