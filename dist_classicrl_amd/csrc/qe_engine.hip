@@ -620,6 +620,9 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         HIP_TRY(env->turn_next.ensure(words));
         HIP_TRY(env->turn_prog.ensure(words));
         c.turn_next = env->turn_next.p; c.turn_prog = env->turn_prog.p;
+        // list heads carry a 32-bit step tag and are never cleared: zero them before a tag can repeat
+        if (((e->turn_epoch + (unsigned long long)steps + 2ull) >> 31) != (e->turn_epoch >> 31) && e->stamps_hold_lists)
+            HIP_TRY(hipMemsetAsync(e->stamps, 0, (size_t)e->S * 2 * sizeof(unsigned long long), e->stream));
         c.turn_epoch = e->turn_epoch;
         e->turn_epoch += (unsigned long long)steps + 2ull;  // tags of this call: epoch .. epoch + steps
         e->stamps_hold_lists = true;

@@ -245,7 +245,7 @@ struct Pending {
 };
 
 template <typename T>
-__device__ __forceinline__ void turn_push(const Ctx<T>& c, int64_t i, int64_t row, int role, long long t1);
+__device__ __forceinline__ void turn_push(const Ctx<T>& c, int64_t i, int64_t row, int role, long long t1, int act);
 
 template <typename T, class Env, int LC = 0>
 __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
@@ -265,8 +265,8 @@ __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx
     const Transition tr = Env::step(ev, i, n, p.aux, act, c.step0 + (unsigned long long)t1);
     if (sub == 0) {
         if (flags & FLAG_TURN) {
-            turn_push(c, i, n, 1, t1);
-            if (tr.next_obs != n) turn_push(c, i, tr.next_obs, 0, t1);
+            turn_push(c, i, n, 1, t1, act);
+            if (tr.next_obs != n) turn_push(c, i, tr.next_obs, 0, t1, 0);
         } else if (!(flags & FLAG_NO_STAMPS)) {
             const int par1 = (int)(t1 & 1);
             touch(c.stamps, n, par1, TOUCH_W);

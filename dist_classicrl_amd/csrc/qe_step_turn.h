@@ -7,8 +7,10 @@
 //
 // * registration (in the PREVIOUS launch, when the transition is selected): each agent pushes itself
 //   on a linked list per touched row -- `head[row][parity]` (the touch-counter array of the other
-//   paths, same layout) is exchanged for {step tag, agent, role}, the old head becomes the agent's
-//   `next`.  A head with another step's tag is an empty list: nothing is ever cleared.
+//   paths, same layout) is exchanged for {step tag : 32 | link : 32}, link = {writer's action : 8 |
+//   agent, role : 24}; the old head's link becomes the agent's `next`.  A head with another step's
+//   tag is an empty list: nothing is cleared per step (the engine zeroes the array before a tag can
+//   repeat).
 // * at the start of the launch the lists are complete (kernel boundary).  An agent walks the list of
 //   the row it writes (role W) and of the row it reads (role R, next observation): K touchers, how
 //   many of them / how many writers among them have a lower agent index, and the lowest toucher,
@@ -24,7 +26,10 @@
 // * table accesses of contested agents and the progress words are device-scope read-modify-write
 //   atomics (they execute at the memory side, the per-XCD L2s are not coherent with each other;
 //   a plain or sc1 load may be served from an L2 line fetched before a remote update).  Uncontested
-//   agents never touch a contested row inside the launch and use plain accesses.
+//   agents never touch a contested row inside the launch and use plain accesses.  The links carry the
+//   writers' actions, so a contested agent re-reads coherently only the COLUMNS somebody else writes
+//   in this step (one or two atomics instead of a whole row); the rest of the row is what it loaded
+//   at the start of the launch.
 //
 // Every spin is bounded: after TURN_SPIN_LIMIT polls an agent gives up, raises ERR_TURN_TIMEOUT and all
 // later launches of the rollout return at once -- every wave exits whatever happens.
@@ -78,9 +83,10 @@ __device__ __forceinline__ Row4<T> load_row4_rmw(T* q, int64_t row, int ld, int 
     return r;
 }
 
-// list head: {tag : 40 | node : 24}, node = ((agent << 1) | role) + 1, 0 = end of list
-__device__ __forceinline__ unsigned long long turn_tag(unsigned long long epoch, long long t) {
-    return (epoch + (unsigned long long)t) & ((1ull << 40) - 1ull);
+// list head: {tag : 32 | link : 32}, link = {action of the writer : 8 | node : 24}, node = ((agent << 1) | role) + 1,
+// node 0 = end of list.  (The engine zeroes the heads before a 32-bit tag can repeat.)
+__device__ __forceinline__ uint32_t turn_tag(unsigned long long epoch, long long t) {
+    return (uint32_t)(epoch + (unsigned long long)t);
 }
 __device__ __forceinline__ int64_t turn_slot(int64_t N, int par, int64_t agent, int role) {
     return (((int64_t)par * N + agent) << 1) | role;
@@ -88,13 +94,13 @@ __device__ __forceinline__ int64_t turn_slot(int64_t N, int par, int64_t agent, 
 
 // Registration of agent i as `role` toucher of `row` in step t1 (one lane per agent).
 template <typename T>
-__device__ __forceinline__ void turn_push(const Ctx<T>& c, int64_t i, int64_t row, int role, long long t1) {
+__device__ __forceinline__ void turn_push(const Ctx<T>& c, int64_t i, int64_t row, int role, long long t1, int act) {
     const int par = (int)(t1 & 1);
-    const unsigned long long tag = turn_tag(c.turn_epoch, t1);
-    const unsigned long long mine = (tag << 24) | (unsigned long long)((((uint32_t)i << 1) | (uint32_t)role) + 1u);
-    const unsigned long long old = atomicExch(&c.stamps[2 * row + par], mine);
+    const uint32_t tag = turn_tag(c.turn_epoch, t1);
+    const uint32_t link = ((uint32_t)(role ? act : 0) << 24) | ((((uint32_t)i << 1) | (uint32_t)role) + 1u);
+    const unsigned long long old = atomicExch(&c.stamps[2 * row + par], ((unsigned long long)tag << 32) | link);
     const int64_t slot = turn_slot(c.N, par, i, role);
-    c.turn_next[slot] = (old >> 24) == tag ? (uint32_t)(old & 0xFFFFFFull) : 0u;
+    c.turn_next[slot] = (uint32_t)(old >> 32) == tag ? (uint32_t)old : 0u;
     c.turn_prog[slot] = 0u;
 }
 
@@ -102,26 +108,49 @@ struct TurnWalk {
     int K, writers;          // touchers of the row, writers among them
     int lower, lower_w;      // touchers / writers with a lower agent index than the walker
     int64_t prog;            // slot of the row's progress word (the lowest toucher's)
+    // columns (actions < 64; bit 63 also stands for every action >= 63) written in this step by a lower
+    // writer / by any writer other than the walker: only these can differ from the row as it was before the step
+    unsigned long long cols_lower, cols_other;
 };
 
 // `h` = the row's list head, `own_next` = the walker's own link on this row (loaded early, coalesced)
 template <typename T>
 __device__ __forceinline__ TurnWalk turn_walk(const Ctx<T>& c, unsigned long long h, uint32_t own_next, int par,
-                                              unsigned long long tag, int64_t i) {
-    TurnWalk w{0, 0, 0, 0, 0};
-    uint32_t node = (h >> 24) == tag ? (uint32_t)(h & 0xFFFFFFull) : 0u;
+                                              uint32_t tag, int64_t i) {
+    TurnWalk w{0, 0, 0, 0, 0, 0ull, 0ull};
+    uint32_t link = (uint32_t)(h >> 32) == tag ? (uint32_t)h : 0u;
     int64_t lowest = INT64_MAX;
     // (a list holds every agent at most once: an agent pushes one node per row)
-    for (int64_t guard = 0; node != 0u && guard <= c.N; ++guard) {
+    for (int64_t guard = 0; (link & 0xFFFFFFu) != 0u && guard <= c.N; ++guard) {
+        const uint32_t node = link & 0xFFFFFFu;
         const int64_t j = (int64_t)((node - 1u) >> 1);
         const int role = (int)((node - 1u) & 1u);
         ++w.K;
         w.writers += role;
+        if (role && j != i) {
+            const uint32_t col = link >> 24;
+            const unsigned long long bit = 1ull << (col < 63u ? col : 63u);
+            w.cols_other |= bit;
+            if (j < i) w.cols_lower |= bit;
+        }
         if (j < i) { ++w.lower; w.lower_w += role; }
         if (j < lowest) { lowest = j; w.prog = turn_slot(c.N, par, j, role); }
-        node = j == i ? own_next : c.turn_next[turn_slot(c.N, par, j, role)];
+        link = j == i ? own_next : c.turn_next[turn_slot(c.N, par, j, role)];
     }
     return w;
+}
+
+// Coherent re-read of the columns in `cols` (see TurnWalk) of a row held in registers.
+template <typename T>
+__device__ __forceinline__ void patch_row4_rmw(Row4<T>& r, T* q, int64_t row, int ld, int sub, unsigned long long cols) {
+    const int c0 = 4 * sub;
+    if (c0 >= ld) return;
+    uint32_t m4 = c0 < 60 ? (uint32_t)(cols >> c0) & 0xFu : ((cols >> 63) ? 0xFu : 0u);
+    if (c0 == 60) m4 = ((uint32_t)(cols >> 60) & 0x7u) | ((cols >> 63) ? 0x8u : 0u);
+    T* p = q + row * ld + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if ((m4 >> j) & 1u) r.v[j] = rmw_read(p + j);
 }
 
 template <typename T, class Env, int LC = 0>
@@ -138,7 +167,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
             advance_agent<T, Env, LC>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t, flags);
         } else {
             const int par = (int)(t & 1);
-            const unsigned long long tag = turn_tag(c.turn_epoch, t);
+            const uint32_t tag = turn_tag(c.turn_epoch, t);
             const int32_t s = c.s[i];
             const bool sep = n != s;
             // everything whose address is known now is requested now (one memory round trip)
@@ -153,7 +182,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
             const Hyper hyper = make_hyper(c, c.lr[t]);
             const uint32_t valid = Env::valid4(ev, i, n, sub);
             const TurnWalk ws = turn_walk(c, head_s, own.y, par, tag, i);
-            TurnWalk wn{0, 0, 0, 0, 0};
+            TurnWalk wn{0, 0, 0, 0, 0, 0ull, 0ull};
             if (sep) wn = turn_walk(c, head_n, own.x, par, tag, i);
             const bool cont_s = ws.K > 1;                        // I write s: any second toucher orders us
             const bool cont_n = sep && wn.K > 1 && wn.writers > 0;  // readers alone never conflict
@@ -179,13 +208,19 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                 uint32_t* const prog_s = c.turn_prog + ws.prog;
                 uint32_t* const prog_n = c.turn_prog + wn.prog;
                 const int W = LC ? LC : c.L;
-                if (sub == 0) atomicAdd(&c.ctrl->involved_total, 1ull);
+                {   // statistics: one atomic per wavefront, not one per agent on the same word
+                    const unsigned long long mine = __ballot(sub == 0);
+                    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u)) == 0u && sub == 0)
+                        atomicAdd(&c.ctrl->involved_total, (unsigned long long)__popcll(mine));
+                }
                 // the lowest toucher of its rows starts at once
                 const bool wait_s = cont_s && ws.lower > 0, wait_n = cont_n && wn.lower_w > 0;
                 // writers of the row my NEXT action is selected from that come after me in the order
                 const int later_w = sep ? (cont_n ? wn.writers - wn.lower_w : 0) : ws.writers - ws.lower_w - 1;
-                // row n is read coherently where somebody else writes it in this step
-                const bool live_n = sep ? cont_n : true;
+                // the row my update reads and my next action is selected from: only the columns somebody else
+                // writes in this step can differ from what I loaded at the start (coherent re-reads of those)
+                const TurnWalk& wr = sep ? wn : ws;
+                const unsigned long long cell_bit = 1ull << (a < 63 ? a : 63);
                 int phase = 0;
                 for (int spin = 0; phase < 2; ++spin) {
                     if (spin >= TURN_SPIN_LIMIT) {  // never expected: give up, every later launch returns at once
@@ -203,9 +238,9 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                         }
                         if (wait_s || wait_n) ok = __shfl(ok, 0, W);
                         if (ok) {
-                            T q0 = 0;
-                            if (sub == 0) q0 = rmw_read(c.q + cell);  // (pred may predate a lower agent's write)
-                            if (live_n) row = load_row4_rmw(c.q, n, c.ld, sub);
+                            T q0 = pred;  // = the table, unless a lower agent has written my cell in this step
+                            if (sub == 0 && (ws.cols_lower & cell_bit)) q0 = rmw_read(c.q + cell);
+                            patch_row4_rmw(row, c.q, n, c.ld, sub, wr.cols_lower);
                             const T m = row_max_valid<LC>(row, valid, c.L);
                             T u;
                             const T q1 = Td<T>::apply(q0, r, m, term, hyper, c.mode, &u);
@@ -242,7 +277,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                         ok = __shfl(ok, 0, W);
                         if (ok) {
                             if (flags & FLAG_SELECT) {
-                                row = load_row4_rmw(c.q, n, c.ld, sub);
+                                patch_row4_rmw(row, c.q, n, c.ld, sub, wr.cols_other | (sep ? 0ull : cell_bit));
                                 advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
                             }
                             phase = 2;
