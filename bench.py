@@ -205,13 +205,18 @@ def main() -> None:
         rt.sync_every = SYNC_EVERY
         rt.delta_sync = attach_engine(algo, SYNC_EVERY, n)
 
-    def sync_all():
+    def device_sync():
         if use_dist:
             import torch
 
-            dist.barrier()
             torch.cuda.synchronize()
         algo._lib.qe_synchronize(algo.handle)
+
+    def sync_all():
+        device_sync()
+        if use_dist:
+            dist.barrier()
+            device_sync()
 
     def run_steps(steps, state):
         """`run_steps`; the reference divides by the number of finished episodes (single_thread_runtime.py:67),
@@ -235,8 +240,12 @@ def main() -> None:
     t0 = time.perf_counter()
     sd = run_steps(args.steps, sd)  # EXACTLY K timed vector steps
     t_call = time.perf_counter() - t0
-    sync_all()
+    # the region closes as it opened, with the device drained and a barrier: every rank stops its clock when ITS
+    # K steps are complete on the device, the slowest rank's time is the job's (MAX over ranks below) -- the
+    # barrier's own latency (tens of microseconds, a large fraction of a 20-step call) is not step time
+    device_sync()
     elapsed = time.perf_counter() - t0
+    sync_all()
     stats = dict(rt.last_stats)
     if use_dist:
         import torch

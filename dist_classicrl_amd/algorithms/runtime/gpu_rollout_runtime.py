@@ -287,9 +287,20 @@ class GpuRolloutQLearning(BaseRuntime):
             # left the GPU.
             env.restore(curr_state_dict["states"], curr_state_dict["rewards"], curr_state_dict.get("aux"))
         collect_trace = self.trace_actions is not None and self.trace_actions is not False
-        if (self.delta_sync is None and not collect_trace and not env.masked and 0 < steps <= env.chunk_limit(True)
-                and self.history_type == "float"):
+        # (replicas: a call that does not cross the exchange cadence only appends to the delta log -- the kernels
+        # write it either way -- and takes the same one-call path as a single GPU; if it ends exactly on the
+        # cadence the exchange follows it)
+        sync = self.delta_sync
+        if (not collect_trace and not env.masked and 0 < steps <= env.chunk_limit(True) and self.history_type == "float"
+                and (sync is None or self._since_sync + steps <= self.sync_every)):
             rets, total, state_dict = self._run_steps_fused(steps, env)
+            if sync is not None:
+                self._since_sync += steps
+                if self._since_sync == self.sync_every:  # the call ended on the cadence: exchange now, as _rollout would
+                    sync.exchange(self._since_sync * env.num_agents)
+                    _lib.check(_lib.load().qe_delta_log_reset(self.algorithm.handle))
+                    self._since_sync = 0
+                    sync.flush()
             reward_history = rets.tolist()
         else:
             rets, _ = self._rollout(env, steps, learn=True)

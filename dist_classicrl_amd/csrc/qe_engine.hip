@@ -690,6 +690,9 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             else if (HAS_LEAN && lean && block <= 128 && !c.dlog)
                 hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, false>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
                                    e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+            else if (HAS_LEAN && lean && block <= 128 && full)  // the same with the delta log of the replica exchange
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
+                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if (HAS_LEAN && lean && block <= 128)
                 hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, false>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
                                    e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);

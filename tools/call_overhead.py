@@ -10,6 +10,10 @@ from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import Opt
 from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
 from dist_classicrl_amd.environments import HashTabularEnv
 from dist_classicrl_amd.schedules import ExponentialSchedule
+if os.environ.get("WITH_SYNC"):  # (torch sees the GPU before the engine's runtime is up)
+    import torch, torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 timing = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 host_block = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -18,6 +22,10 @@ algo.set_engine_option(_lib.OPT_EVENT_TIMING, timing)
 algo.set_engine_option(_lib.OPT_HOST_BLOCK, host_block)
 env = HashTabularEnv(128, 1_000_000, 16, seed=1)
 rt = GpuRolloutQLearning(algo, ExponentialSchedule(0.1, 1e-5, 0.995), ExponentialSchedule(1.0, 0.01, 0.995))
+if os.environ.get("WITH_SYNC"):  # replica exchange attached (one rank): the path of `bench.py --gpus N` ranks
+    from dist_classicrl_amd.distributed.delta_sync import attach_engine
+    rt.sync_every = 100
+    rt.delta_sync = attach_engine(algo, 100, 128)
 _, _, _, sd = rt.run_steps(2000, env, None)
 reps = int(os.environ.get("REPS", "300"))
 dev = hb = he = 0.0
