@@ -330,7 +330,7 @@ def test_rollout_matches_oracle_seeded(spec, steps, dt, mode, path):
     assert np.array_equal(got["agent_rewards"], want["agent_rewards"])
 
 
-@pytest.mark.parametrize("path", ["stepwise", "persistent", "wide"])
+@pytest.mark.parametrize("path", ["stepwise", "persistent", "wide", "turnstile"])
 def test_rollout_without_selectable_action_raises_like_the_reference(path):
     """A NaN row maximum leaves `np.where(row == max)` empty and the reference's `random.choice` raises
     IndexError (q_learning_optimal.py:563); the fused rollout reports the same instead of writing outside
@@ -367,6 +367,39 @@ def test_rollout_resume_equals_one_shot():
     assert np.array_equal(np.asarray(algo.q_table), one["q"])
     assert np.array_equal(np.array(h1 + h2, dtype=np.float32), one["history"])
     assert np.array_equal(sd["states"], one["final_obs"])
+
+
+def test_switching_rollout_paths_on_one_engine_equals_one_shot():
+    """The turnstile path keeps its row lists in the array the other paths use as touch counters: a run that
+    switches turnstile -> step-wise -> wide -> turnstile -> `learn()` batches on ONE engine equals the one-shot run
+    (the array is handed over zeroed, list tags of earlier calls never match)."""
+    spec = ("hash", 2100, 900, 16, False)
+    one = _run_product_trace(spec, 40, "f4", "bench", "iter", path="stepwise")
+    Algo, Runtime, _, _ = _product()
+    env = make_device_env(spec)
+    algo = Algo(env.state_size, env.action_size, 0.99, seed=0)
+    lr_p, eps_p = schedule_params("bench")
+    rt = Runtime(algo, make_schedule(lr_p), make_schedule(eps_p))
+    sd, history = None, []
+    for path, k in (("turnstile", 9), ("stepwise", 11), ("wide", 7), ("turnstile", 13)):
+        algo.set_rollout_path(path)
+        _, h, env, sd = rt.run_steps(k, env, sd)
+        history += h
+    assert np.array_equal(np.asarray(algo.q_table), one["q"])
+    assert np.array_equal(np.array(history, dtype=np.float32), one["history"])
+    assert np.array_equal(sd["states"], one["final_obs"])
+    # ... and the batch API (its kernels count touches in the same array) still equals the oracle afterwards
+    from oracle.qlearn_oracle import OracleQLearning
+
+    rng = np.random.default_rng(5)
+    n = 600
+    batch = (rng.integers(0, 900, n), rng.integers(0, 16, n), rng.random(n).astype(np.float32),
+             rng.integers(0, 900, n), rng.random(n) < 0.1)
+    ref = OracleQLearning(900, 16, 0.99, seed=0, dtype=np.dtype("f4"))
+    ref.q_table = np.array(one["q"], dtype=np.float32)
+    ref.learn(*[np.array(b) for b in batch], 0.1)
+    algo.learn(*batch, 0.1)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q_table)
 
 
 # ------------------------------------------------------------------------------- full sizes
