@@ -1,6 +1,6 @@
 """Randomised parity sweep on the GPU box (not part of the test suite): random shapes, dtypes, learn
 modes, schedules and rollout paths, product vs the NumPy oracle, everything compared bit for bit.
-Usage: python tools/fuzz_parity.py <seconds> [seed].  Prints every failing configuration."""
+Usage: python tools/fuzz_parity.py <seconds> [seed] [path].  Prints every failing configuration."""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
@@ -11,9 +11,14 @@ import test_gpu_parity as tp
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only_path = sys.argv[3] if len(sys.argv) > 3 else None  # e.g. "turnstile": every case through that path
 t_end = time.time() + budget
 n_ok = n_bad = n_skip = 0
+t_note = time.time()
 while time.time() < t_end:
+    if time.time() - t_note > 30:
+        t_note = time.time()
+        print(f"... {n_ok} ok, {n_bad} bad, {n_skip} skipped", flush=True)
     kind = rng.choice(["hash", "hash", "hash", "hash", "grid", "bandit", "ttt"])
     if kind == "hash":
         A = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 16, 17, 32, 33, 64, 70]))
@@ -31,7 +36,9 @@ while time.time() < t_end:
     dt = str(rng.choice(["f4", "f8"]))
     mode = str(rng.choice(["iter", "iter", "vec"]))
     sched = str(rng.choice(["const", "bench", "linear"]))
-    path = str(rng.choice(["auto", "stepwise", "persistent", "wide", "wide_listed"]))
+    path = str(rng.choice(["auto", "stepwise", "persistent", "wide", "wide_listed", "turnstile", "turnstile"]))
+    if only_path:
+        path = only_path
     cfg = (spec, steps, dt, mode, sched, path)
     try:
         try:
