@@ -598,11 +598,13 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
                     if (tid == 0 && lds.n_def > 0u) reinterpret_cast<const Ctx<T>*>(lds.cold)->ctrl->error = 2u;
                 }
             }
-            // every update of step t is in the table: late selections read their row again
+            // every update of step t is in the table: late selections read their row again -- unless nobody
+            // wrote it in this step (an agent whose UPDATE had to wait, e.g. the second of two agents in one
+            // state that move on to the same successor: the row gathered before the step is still the row)
             if (active && cls != 3 && !last) {
-                RowV<T, NV> fresh;
-                load_row_lane<NV>(fresh, c.q, p.n);
-                advance(fresh, valid, t + 1, x, thr_t1);
+                const bool untouched = __all((cls & 2) && p.n != p.s);  // (one decision per wavefront)
+                if (!untouched) load_row_lane<NV>(row, c.q, p.n);
+                advance(row, valid, t + 1, x, thr_t1);
             }
             if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }
             __builtin_amdgcn_s_waitcnt(0x0F70);  // (busy step: nothing in flight on any path, see above)
