@@ -506,7 +506,9 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
             }
         }
         QL_STAMP(4);
-        if (active && cls == 3 && !last) advance(row, valid, t + 1, x, thr_t1);
+        // (a busy step selects for ALL its agents in one pass, after its ordered updates: executing the
+        // selection + env.step code twice per wavefront costs more than the few lanes of the second pass save)
+        if (active && !busy && !last) advance(row, valid, t + 1, x, thr_t1);
         QL_STAMP(5);
 
         if (busy) {
@@ -601,9 +603,8 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
             // every update of step t is in the table: late selections read their row again -- unless nobody
             // wrote it in this step (an agent whose UPDATE had to wait, e.g. the second of two agents in one
             // state that move on to the same successor: the row gathered before the step is still the row)
-            if (active && cls != 3 && !last) {
-                const bool untouched = __all((cls & 2) && p.n != p.s);  // (one decision per wavefront)
-                if (!untouched) load_row_lane<NV>(row, c.q, p.n);
+            if (active && !last) {
+                if (cls != 3 && !((cls & 2) && p.n != p.s)) load_row_lane<NV>(row, c.q, p.n);
                 advance(row, valid, t + 1, x, thr_t1);
             }
             if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }

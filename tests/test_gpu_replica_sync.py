@@ -30,6 +30,8 @@ def test_one_rank_exchange_equals_plain_run(n, S, A, steps, sync_every):
     torch = pytest.importorskip("torch")
     import torch.distributed as dist
 
+    torch.cuda.set_device(0)  # torch's HIP runtime must see the GPU before the engine's does (two runtimes, one process)
+
     from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
     from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
     from dist_classicrl_amd.distributed.delta_sync import attach_engine
@@ -72,6 +74,8 @@ def test_short_calls_below_the_exchange_cadence_equal_the_plain_run():
     which the 50th logged step falls exchanges; tables, returns and states equal the plain run bit for bit."""
     torch = pytest.importorskip("torch")
     import torch.distributed as dist
+
+    torch.cuda.set_device(0)  # torch's HIP runtime must see the GPU before the engine's does (two runtimes, one process)
 
     from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
     from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
