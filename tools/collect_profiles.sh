@@ -18,6 +18,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/headline_pmc_$name" -- $BENCH > "$OUT/headline_pmc_$name.log" 2>&1 || exit 1
 done
 fi
+[ "${ONLY_HEADLINE:-0}" = 1 ] && { echo "headline profiles collected under $OUT"; exit 0; }
 # 3. ONE attempt at the graph-replay path under the profiler (rocprofv3 7.2 has been seen to segfault when a
 #    captured HIP graph is replayed under --kernel-trace): whatever happens is kept as evidence
 ( cd /tmp; QE_USE_GRAPH=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c3_graph_stats" -- python3 $ROOT/bench.py --workload c3 --steps 1000 --warmup 1000 --no-cpu-baseline > "$OUT/c3_graph_under_rocprofv3.log" 2>&1; echo "exit code $?" >> "$OUT/c3_graph_under_rocprofv3.log" )
