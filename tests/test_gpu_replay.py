@@ -89,6 +89,8 @@ def test_replay_errors():
     (96, 500, 8, 25, 96 * 25 + 17, "auto"),      # persistent kernel, everything fits the ring
     (96, 500, 8, 40, 1000, "auto"),              # ... and wrapping around it
     (600, 3000, 16, 12, 600 * 12, "stepwise"),   # step-wise kernels
+    (600, 3000, 16, 12, 600 * 12, "auto"),       # one launch per step (turnstile path)
+    (2100, 3000, 16, 9, 5000, "wide"),           # token rounds
 ])
 def test_fused_rollout_pushes_every_transition_into_the_ring(n, S, A, steps, capacity, path):
     """experience_replay.py:68-86 wired to the fused loop: the ring holds (s, a, r, s', done) of every agent and
