@@ -28,6 +28,8 @@ from dist_classicrl_amd.schedules import ExponentialSchedule, LinearSchedule
 def make(kind, dtype):
     if kind == "hash":
         env = HashTabularEnv(96, 3000, 16, seed=1)
+    elif kind == "hash_many":  # above the persistent kernel's 512 agents: one launch per step (turnstile path)
+        env = HashTabularEnv(700, 900, 16, seed=1)
     elif kind == "hash_masked":
         env = HashTabularEnv(64, 700, 12, seed=3, masked=True)
     elif kind == "ttt":
@@ -78,6 +80,7 @@ def _run(code):
     ("hash_masked", "float64", 40, 40),   # masked observations (dict states), float64 table
     ("ttt", "float32", 60, 50),           # env-internal state = the boards
     ("bandit", "float64", 9, 12),         # env-internal state = position inside the episode
+    ("hash_many", "float32", 30, 25),     # 700 agents on 900 states: every step has chains of row sharers
 ])
 def test_save_load_resume_in_a_fresh_process_equals_continuing(tmp_path, kind, dtype, k1, k2):
     table, state = str(tmp_path / "table.npy"), str(tmp_path / "state.pkl")
