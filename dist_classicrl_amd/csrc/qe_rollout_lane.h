@@ -405,7 +405,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         const bool busy = lds.busy[t & 3] != 0u;
         const U4 x = draws(t + 1);
         if (helper && !last && !QX(5)) produce(t + 2);
-        if (stale) load_row_lane<NV>(row, c.q, p.n);
+        if (stale && !QX(8)) load_row_lane<NV>(row, c.q, p.n);
         const M valid = valid_mask_lane<Env, NV, MASKED>(ev, ii, p.n);
         QL_STAMP(0);
         // ---- busy step: exact registration of every touch, then classification ---------------------
