@@ -219,6 +219,8 @@ struct qe_engine {
     int64_t listed_min = LISTED_MIN_AGENTS;  // QE_OPT_LISTED_MIN_AGENTS
     int opt_timing = 1;  // QE_OPT_EVENT_TIMING: bracket rollouts with HIP events (persistent path: off = in-kernel clock only)
     int opt_host_block = 1;  // QE_OPT_HOST_BLOCK: persistent rollouts publish through the host result block
+    int opt_lane_ordered = 0;  // QE_OPT_LANE_ORDERED_PATH: 0 = automatic, 1 = light build (sequential fallback), 2 = full build
+    int lane_light = -1;       // automatic choice for the next launch (-1: not decided yet)
     unsigned long long seq_ctr = 0;
     double host_begin_us = 0.0;  // diagnostics (QE_PRINT_HOST)
     hipStream_t stream = nullptr;
@@ -684,7 +686,18 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                                       ((std::is_same<Env, HashEnv>::value && !MK && (NV == 2 || NV == 4)) ||
                                        std::is_same<Env, TttEnv>::value);
             const bool full = (int64_t)block == env->N;  // every lane of the agents' wavefronts holds an agent
-            if (HAS_LEAN && lean && block <= 128 && !c.dlog && full)  // (+ one draw-producing wavefront per wavefront of agents)
+            // The build without the general ordered path (SEQ, see the kernel) where steps with more than two
+            // touchers on a row are rare: expected from the shape at first (agents^2 / states), from the
+            // previous launch's count afterwards.
+            if (e->lane_light < 0) e->lane_light = (double)env->N * (double)env->N < 0.1 * (double)e->S ? 1 : 0;
+            const bool light = e->opt_lane_ordered == 1 || (e->opt_lane_ordered == 0 && e->lane_light == 1);
+            if (HAS_LEAN && lean && block <= 128 && !c.dlog && full && light)
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
+                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+            else if (HAS_LEAN && lean && block <= 128 && full && light)  // ... with the delta log of the replica exchange
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
+                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
+            else if (HAS_LEAN && lean && block <= 128 && !c.dlog && full)  // (+ one draw-producing wavefront per wavefront of agents)
                 hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
                                    e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if (HAS_LEAN && lean && block <= 128 && !c.dlog)
@@ -813,6 +826,7 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
     if (sl.fast) {
         if (int rc = wait_host_block(e, sl)) return rc;
         fin.ep_count = sl.hb->ep_count; fin.involved_total = sl.hb->involved_total; fin.error = sl.hb->error;
+        fin.pending_total = sl.hb->complex_steps;
         clock_ms = (double)(sl.hb->clk1 - sl.hb->clk0) / e->wall_clock_khz;
         if (getenv("QE_PRINT_CLOCK") && sl.hb->clk1 > sl.hb->clk0)
             fprintf(stderr, "  [clock] %.0f MHz shader clock over %.1f us (%lld steps)\n",
@@ -841,6 +855,13 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         if (sl.steps > 0) e->ms_per_step_est = clock_ms / (double)sl.steps;
     } else {
         ms = (float)(e->ms_per_step_est * (double)sl.steps);
+    }
+    if (sl.persistent && sl.steps > 0) {
+        // Which build of the persistent kernel the NEXT launches take (see SEQ in qe_rollout_lane.h): the full one
+        // as soon as more than 1 % of a launch's steps needed the general ordered path, the light one again after
+        // a launch of some length without any.
+        if ((double)fin.pending_total > 0.01 * (double)sl.steps) e->lane_light = 0;
+        else if (fin.pending_total == 0 && sl.steps >= 64) e->lane_light = 1;
     }
     if (sl.wide && sl.steps > 0) {
         // Number of chip-wide token rounds of the NEXT calls: every round roughly halves the agents that
@@ -1089,6 +1110,7 @@ int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_TOKEN_ROUNDS && value >= 0 && value <= MAX_TOKEN_ROUNDS) { e->opt_rounds = (int)value; return QE_OK; }
     if (option == QE_OPT_EVENT_TIMING && (value == 0 || value == 1)) { e->opt_timing = (int)value; return QE_OK; }
     if (option == QE_OPT_HOST_BLOCK && (value == 0 || value == 1)) { e->opt_host_block = (int)value; return QE_OK; }
+    if (option == QE_OPT_LANE_ORDERED_PATH && value >= 0 && value <= 2) { e->opt_lane_ordered = (int)value; return QE_OK; }
     return fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 

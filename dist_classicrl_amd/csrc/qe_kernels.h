@@ -89,7 +89,8 @@ struct HostBlock {
     unsigned long long involved_total;  // agents that reached the ordered path
     unsigned long long clk0, clk1;      // s_memrealtime (100 MHz) at the start / end of the launch
     unsigned long long cyc0, cyc1;      // s_memtime (shader clock) at the same two points
-    unsigned int error, pad;
+    unsigned int error;
+    unsigned int complex_steps;         // steps in which a contested row had more than two touchers
 };
 
 // Schedule values of a short rollout travel in the kernel-argument segment (first parameter of the

@@ -208,6 +208,7 @@ struct LaneLds {
     unsigned ep_n;
     unsigned n_def;       // agents whose update is deferred in this step
     unsigned complex_;    // a contested row has more than two touchers
+    int seq_min[2];       // SEQ builds: lowest pending agent of the current / the next round of a complex step
 };
 
 #ifdef QE_EXPERIMENT
@@ -235,7 +236,15 @@ __device__ __forceinline__ void step_barrier() {
 // and operands from the loop.
 // FULL: every lane of the agents' wavefronts holds an agent (N is a multiple of 64), so "this lane is
 // active" is a per-wavefront fact and the per-agent sections need no exec-mask bookkeeping.
-template <typename T, class Env, int NV, int CAP, bool MASKED, int LEAN = 0, bool HELP = false, bool FULL = false>
+// SEQ: the kernel is built WITHOUT the general ordered path (slow_body).  Inlined, that path's register
+// demand makes the whole loop spill ~100 scalars to lanes (132 v_readlane and 154 VGPRs in the kernel against
+// 1 and 112 without it; called out of line instead, the call's register constraints cost more than the
+// spills).  A step in which some contested row has more than two touchers -- none in 20 000 steps of the
+// benchmark schedule -- is then worked off one deferred agent per round, lowest index first (every
+// dependency points from a lower to a higher index): exact, slow (~1.5 us per deferred agent), and counted,
+// so that the engine takes the full build for the following launches when such steps are not rare.
+template <typename T, class Env, int NV, int CAP, bool MASKED, int LEAN = 0, bool HELP = false, bool FULL = false,
+          bool SEQ = false>
 __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSched /*at offset 0 of the kernarg segment*/,
                                                                        Ctx<T> c, EnvCtx ev, long long steps, int flags) {
     using M = typename LaneMask<NV>::type;
@@ -273,6 +282,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
     p.s = 0; p.a = 0; p.pred = 0; p.r = 0.0f; p.term = false;
     float acc = c.acc[ii];
     unsigned long long deferred_total = 0, ep_base = 0;
+    unsigned complex_steps = 0;
     // my entries of the written-rows sets of steps t+1, t, t-1 (dump slot: none)
     int w_next = WT, w_cur = WT, w_prev = WT;
     const int flush_every = 32;  // steps per flush window of the staged episode log
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
     if (tid == 0) {
         *reinterpret_cast<Ctx<T>*>(lds.cold) = c;
         lds.ep_n = 0u; lds.n_def = 0u; lds.complex_ = 0u;
+        lds.seq_min[0] = 0x7FFFFFFF; lds.seq_min[1] = 0x7FFFFFFF;
         for (int k = 0; k < 5; ++k) lds.busy[k] = 0u;
         c.ctrl->error = 0u;  // this launch owns the control block: no host-side memset in front of it
         c.ctrl->inv_count = 0u;
@@ -527,7 +538,36 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
 #endif
             if (n_def > 0) {
                 deferred_total += (unsigned long long)n_def;
-                if (lds.complex_) {
+                if (lds.complex_) ++complex_steps;
+                if constexpr (SEQ) if (lds.complex_) {
+                    // (build without the general ordered path) one deferred agent per round, lowest index first
+                    bool mine = active && !(cls & 1);
+                    for (int round = 0; round <= n_def; ++round) {
+                        if (mine) atomicMin(&lds.seq_min[round & 1], i);
+                        barrier_lds();
+                        const int turn = lds.seq_min[round & 1];
+                        if (tid == 0) lds.seq_min[(round + 1) & 1] = 0x7FFFFFFF;  // (last read before this barrier)
+                        if (turn == 0x7FFFFFFF) break;
+                        if (mine && i == turn) {
+                            T m = 0;
+                            if (!p.term) {
+                                RowV<T, NV> fresh;
+                                load_row_lane<NV>(fresh, c.q, p.n);
+                                m = row_max_lane(masked_row<MASKED>(fresh, valid));
+                            }
+                            const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
+                            const T q0 = c.q[cell];
+                            T u;
+                            c.q[cell] = Td<T>::apply(q0, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
+                            log_delta(c, t, i, cell, u);
+                            lds.pending[i] = 0;
+                            mine = false;
+                        }
+                        __syncthreads();  // this round's table write is complete and visible
+                    }
+                    if (tid == 0) { lds.seq_min[0] = 0x7FFFFFFF; lds.seq_min[1] = 0x7FFFFFFF; }
+                }
+                if (!SEQ && lds.complex_) {
                     // general case: hand the deferred transitions to slow_body, which views the rows
                     // through lane groups of its own (c.L lanes per row)
                     const Ctx<T>& cold = *reinterpret_cast<const Ctx<T>*>(lds.cold);
@@ -567,7 +607,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
                         slow_body<T, Env, CAP, PERSIST_CACHE_BYTES, NV>(cc, ev, FLAG_NO_STAMPS | FLAG_LEARN, t, n_def, lds.slow);
                     }
                     __syncthreads();
-                } else {
+                } else if (!lds.complex_) {
                     // every contested row has two touchers: the second one follows the first, in place.
                     // lds.n_def itself counts down (every wave has copied it into `n_def` above)
                     bool mine = active && !(cls & 1);
@@ -674,6 +714,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
     }
     if (tid == 0) {
         cc.ctrl->involved_total = deferred_total;
+        cc.ctrl->pending_total = complex_steps;
         cc.ctrl->ep_count = ep_base;
         cc.ctrl->t_local = steps;
     }
@@ -687,6 +728,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
             hb->ep_count = ep_base;
             hb->involved_total = deferred_total;
             hb->error = cc.ctrl->error;
+            hb->complex_steps = complex_steps;
             hb->clk0 = clk0;
             hb->clk1 = wall_clock64();
             hb->cyc0 = cyc0;

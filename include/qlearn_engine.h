@@ -108,7 +108,10 @@ enum qe_option { QE_OPT_ROLLOUT_PATH = 0, QE_OPT_USE_GRAPH = 1 /* 1 (default): r
                                             report the in-kernel clock only and put no event into the stream */,
                  QE_OPT_HOST_BLOCK = 5 /* 1 (default): a persistent rollout writes its results (control words, final observations,
                                           episode log) into page-locked host memory itself and qe_rollout_end spins on a sequence
-                                          word there; 0: stream synchronisation + copies */ };
+                                          word there; 0: stream synchronisation + copies */,
+                 QE_OPT_LANE_ORDERED_PATH = 6 /* persistent kernel, up to 128 agents: 0 (default) = automatic, 1 = the build without the
+                                                 general ordered path (steps with more than two touchers on a row are worked off one
+                                                 agent per round), 2 = the build with it */ };
 int qe_set_option(qe_engine* e, int32_t option, int64_t value);
 
 /* ---- Q-table I/O ----------------------------------------------------------------------------

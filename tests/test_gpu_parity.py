@@ -225,13 +225,19 @@ def test_learn_vec_many_collisions_stay_exact():
 
 
 # ------------------------------------------------------------------------------- closed loop
-PATHS = ["stepwise", "persistent", "wide", "wide_listed", "turnstile"]
+PATHS = ["stepwise", "persistent", "persistent_light", "wide", "wide_listed", "turnstile"]
 
 
 def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="auto"):
     Algo, Runtime, _, _ = _product()
     env = make_device_env(spec)
     algo = Algo(env.state_size, env.action_size, gamma, seed=seed, dtype=np.dtype(dt))
+    if path == "persistent_light":  # the persistent kernel's build without the general ordered path
+        if env.num_agents > 128 or env.num_agents % 64 or dt != "f4" or mode != "iter":
+            pytest.skip("the light build exists for float32 learn_iter rollouts of 64 or 128 agents")
+        from dist_classicrl_amd import _lib
+        algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, 1)
+        path = "persistent"
     if path == "persistent" and (env.action_size > 64 or env.num_agents > 512):
         pytest.skip("more than 512 agents / 64 actions: the persistent kernel does not apply")
     if path == "turnstile" and mode != "iter":
@@ -303,6 +309,9 @@ def test_rollout_matches_reference_golden(name, path):
         (("hash", 6000, 100000, 12, True), 12, "f4", "vec"),  # > 2048 involved agents in learn_vec: batched, exact
         (("hash", 2500, 40, 16, False), 20, "f4", "vec"),
         (("hash", 4096, 2000, 9, True), 16, "f8", "vec"),
+        (("hash", 128, 60, 16, False), 60, "f4", "iter"),  # two wavefronts of agents on 60 states: every step complex
+        (("hash", 64, 25, 8, False), 50, "f4", "iter"),
+        (("hash", 128, 4000, 16, False), 80, "f4", "iter"),  # mostly quiet / two-toucher steps, a few complex ones
         (("hash", 128, 700, 32, False), 60, "f4", "iter"),  # persistent, 8 lanes per row
         (("hash", 64, 300, 64, True), 60, "f8", "iter"),  # persistent, 16 lanes per row
         (("hash", 60, 500, 50, False), 70, "f4", "iter"),  # 16 lanes per row, A not a multiple of 4
@@ -319,7 +328,7 @@ def test_rollout_matches_reference_golden(name, path):
 )
 @pytest.mark.parametrize("path", PATHS)
 def test_rollout_matches_oracle_seeded(spec, steps, dt, mode, path):
-    if path == "persistent" and spec[1] > 512:
+    if path in ("persistent", "persistent_light") and spec[1] > 512:
         pytest.skip("more than 512 agents: the persistent kernel does not apply")
     want = run_oracle_trace(spec, steps, dt, "const", mode)
     got = _run_product_trace(spec, steps, dt, "const", mode, path=path)
