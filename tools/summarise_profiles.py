@@ -54,7 +54,7 @@ out = {
     "headline": {
         "command": "rocprofv3 --kernel-trace --pmc <counter group> --output-format csv -- python3 bench.py --steps 20000 "
                    "--warmup 2000 --no-cpu-baseline (one pass per group: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)",
-        "kernel": "k_rollout_lane<float, HashEnv, 4, 128, false, 1, true, true>",
+        "kernel": "k_rollout_lane<float, HashEnv, 4, 128, false, 1, true, true, true> (the build without the general ordered path; 2 of the 94 launches took the build with it)",
         "launches": n1,
         "env_steps_all_launches": env_steps,
         "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
