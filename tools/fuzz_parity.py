@@ -31,10 +31,17 @@ while time.time() < t_end:
         spec = ("bandit", int(rng.choice([1, 2, 300, 600])), int(rng.choice([1, 4, 7])))
     else:
         spec = ("ttt", int(rng.choice([1, 64, 128, 600])))
+    if only_path == "persistent_light":  # the shapes that build exists for
+        if kind == "hash":
+            spec = ("hash", int(rng.choice([64, 128])), int(rng.choice([5, 40, 300, 2000, 20000, 100000])), int(rng.choice([5, 8, 9, 12, 16])), False)
+        elif kind == "ttt":
+            spec = ("ttt", int(rng.choice([64, 128])))
     n_agents = spec[1]
     steps = int(min(rng.integers(3, 70), max(3, 150_000 // max(1, n_agents))))
     dt = str(rng.choice(["f4", "f8"]))
     mode = str(rng.choice(["iter", "iter", "vec"]))
+    if only_path == "persistent_light":
+        dt, mode = "f4", "iter"
     sched = str(rng.choice(["const", "bench", "linear"]))
     path = str(rng.choice(["auto", "stepwise", "persistent", "wide", "wide_listed", "turnstile", "turnstile"]))
     if only_path:
