@@ -13,7 +13,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 only_path = sys.argv[3] if len(sys.argv) > 3 else None  # e.g. "turnstile": every case through that path
 t_end = time.time() + budget
-n_ok = n_bad = n_skip = 0
+n_ok = n_bad = n_skip = n_div = 0
 t_note = time.time()
 while time.time() < t_end:
     if time.time() - t_note > 30:
@@ -75,8 +75,12 @@ while time.time() < t_end:
     ok = all(np.array_equal(got[k], want[k], equal_nan=(k == "q")) for k in ("actions", "q", "history", "final_obs", "agent_rewards", "final_sched"))
     if ok:
         n_ok += 1
+    elif not np.isfinite(want["q"]).all() and all(np.array_equal(got[k], want[k]) for k in ("actions", "history", "final_obs")):
+        # the known divergence: the oracle's table has overflowed to inf / NaN (lr = 1, learn_vec,
+        # hundreds of colliding increments); NumPy's max propagates NaN, the kernels' does not
+        n_div += 1
     else:
         n_bad += 1
         which = [k for k in ("actions", "q", "history", "final_obs", "agent_rewards", "final_sched") if not np.array_equal(got[k], want[k], equal_nan=(k == "q"))]
         print("MISMATCH", cfg, which, flush=True)
-print(f"fuzz: {n_ok} ok, {n_bad} bad, {n_skip} skipped")
+print(f"fuzz: {n_ok} ok, {n_bad} bad, {n_skip} skipped, {n_div} in the known NaN regime (tables differ, actions equal)")
