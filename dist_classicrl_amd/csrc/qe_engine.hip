@@ -691,11 +691,12 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             // previous launch's count afterwards.
             if (e->lane_light < 0) e->lane_light = (double)env->N * (double)env->N < 0.1 * (double)e->S ? 1 : 0;
             const bool light = e->opt_lane_ordered == 1 || (e->opt_lane_ordered == 0 && e->lane_light == 1);
+            // (no wavefronts beyond the agents' and the draw producers': the others only serve the general ordered path)
             if (HAS_LEAN && lean && block <= 128 && !c.dlog && full && light)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(2 * block), 0,
                                    e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if (HAS_LEAN && lean && block <= 128 && full && light)  // ... with the delta log of the replica exchange
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
+                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(2 * block), 0,
                                    e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
             else if (HAS_LEAN && lean && block <= 128 && !c.dlog && full)  // (+ one draw-producing wavefront per wavefront of agents)
                 hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
