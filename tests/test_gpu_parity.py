@@ -457,6 +457,8 @@ def test_full_size_properties(n, S, A, masked):
         ("c3", 4096, 1_000_000, 16, False, 150),
         ("c5", 1024, 1_000_000, 64, True, 100),
         ("c4-one-shard", 8192, 10_000_000, 32, False, 40),
+        ("just-resident", 30_000, 200_000, 16, False, 25),  # 469 workgroups: the largest grids the turnstile path takes
+        ("not-resident", 40_000, 200_000, 16, False, 20),   # 625 workgroups: back to the wide path
     ],
 )
 def test_full_size_bit_exact_against_c_oracle(name, n, S, A, masked, steps):
