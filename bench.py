@@ -140,6 +140,9 @@ def main() -> None:
     ap.add_argument("--agents", type=int, default=None, help="agents per GPU (default: the workload's)")
     ap.add_argument("--mode", default="iter", choices=["iter", "vec"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--turn-forward", type=int, default=1, choices=[0, 1],
+                    help="turnstile path (513 .. ~60 000 agents): 0 = no value forwarding in the progress words "
+                         "(measurement switch, results are identical)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the ranks; gloo + fewer GPUs than ranks (ranks then share GPUs) is a "
                          "rehearsal of the N > 1 path on a small box, not a measurement")
@@ -195,6 +198,8 @@ def main() -> None:
                              agent_offset=rank * n)
     rt = GpuRolloutQLearning(algo, ExponentialSchedule(0.1, 1e-5, 0.995),
                              ExponentialSchedule(1.0, 0.01, 0.995), learn_mode=args.mode)
+    if not args.turn_forward:
+        algo.set_engine_option(_lib.OPT_TURN_FORWARD, 0)
     if n >= 16384:
         # hundreds of thousands of episodes end per call: take the returns as one float32 array
         # instead of a Python list with one object per episode (the values are the same)

@@ -219,6 +219,7 @@ struct qe_engine {
     int64_t listed_min = LISTED_MIN_AGENTS;  // QE_OPT_LISTED_MIN_AGENTS
     int opt_timing = 1;  // QE_OPT_EVENT_TIMING: bracket rollouts with HIP events (persistent path: off = in-kernel clock only)
     int opt_host_block = 1;  // QE_OPT_HOST_BLOCK: persistent rollouts publish through the host result block
+    int opt_turn_forward = 1;  // QE_OPT_TURN_FORWARD: value forwarding in the progress words of the turnstile path
     int opt_lane_ordered = 0;  // QE_OPT_LANE_ORDERED_PATH: 0 = automatic, 1 = light build (sequential fallback), 2 = full build
     int lane_light = -1;       // automatic choice for the next launch (-1: not decided yet)
     unsigned long long seq_ctr = 0;
@@ -284,7 +285,8 @@ struct qe_env {
     DevBuf<float> r, acc;
     DevBuf<uint8_t> term, pred, masks;
     DevBuf<uint32_t> aux, bitmap, adv_bitmap;
-    DevBuf<uint32_t> turn_next, turn_prog;  // turnstile path: [2][N][2] each, allocated on first use
+    DevBuf<uint32_t> turn_next;            // turnstile path: [2][N][2], allocated on first use
+    DevBuf<unsigned long long> turn_prog;  // turnstile path: [2][N][2] progress words
     DevBuf<double> vinc;
     // host copy of (observations, env-internal state, running returns) left by the latest rollout's
     // result block; valid until anything else changes the device state
@@ -492,7 +494,8 @@ void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& e
     const dim3 grid(grid_for(c.N * c.L, FAST_BLOCK)), block(FAST_BLOCK);
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample], e->stream);
     if (c.turn_next) {  // turnstile path: the whole vector step is this one launch (qe_step_turn.h)
-        hipLaunchKernelGGL((k_step_turn<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags | FLAG_TURN);
+        hipLaunchKernelGGL((k_step_turn<T, Env, LC>), grid, block, 0, e->stream, c, ev,
+                           flags | FLAG_TURN | (e->opt_turn_forward ? 0 : FLAG_TURN_NO_FORWARD));
         if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
         ++sl.launches;
         return;
@@ -746,19 +749,29 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         // lives in the control block), so a block of GRAPH_STEPS of them is captured once per call
         // into a HIP graph and replayed: the host no longer pays one launch per kernel.  The first
         // steps stay eager so that the dominant kernel can be bracketed by events.
-        int64_t done = 0;
+        // (Turnstile path: its launches do not move the step counter themselves; a launch works on step
+        // counter + turn_t_off, `t_base` is the counter's value in stream order.)
+        int64_t done = 0, t_base = 0;
+        auto at_step = [&](int64_t step) { Ctx<T> cc = c; if (turn) cc.turn_t_off = step - t_base; return cc; };
+        auto bump = [&](int64_t by) {
+            hipLaunchKernelGGL(k_turn_bump, dim3(1), dim3(1), 0, e->stream, sl.ctrl, (long long)by);
+            t_base += by;
+        };
         const int64_t middle = steps - 1;
         const int64_t eager_head = std::min<int64_t>(middle, 32);
         for (; done < eager_head; ++done) {
             const int sample = sl.n_samples < MAX_SAMPLES ? sl.n_samples++ : -1;
-            launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true, sample);
+            launch_step_any<T, Env>(e, sl, at_step(done), ev, base | FLAG_LEARN | FLAG_SELECT, true, sample);
         }
         if (e->opt_graph && middle - done >= 2 * GRAPH_STEPS) {
             if (sl.graph_exec) { (void)hipGraphExecDestroy(sl.graph_exec); sl.graph_exec = nullptr; }
+            if (turn) bump(done - t_base);  // the graph's launches count from the counter
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
             const int64_t before = sl.launches;
-            for (int k = 0; k < GRAPH_STEPS; ++k) launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true);
+            for (int k = 0; k < GRAPH_STEPS; ++k)
+                launch_step_any<T, Env>(e, sl, at_step(t_base + k), ev, base | FLAG_LEARN | FLAG_SELECT, true);
+            if (turn) hipLaunchKernelGGL(k_turn_bump, dim3(1), dim3(1), 0, e->stream, sl.ctrl, (long long)GRAPH_STEPS);
             const int64_t per_replay = sl.launches - before;
             sl.launches = before;
             HIP_TRY(hipStreamEndCapture(e->stream, &graph));
@@ -768,10 +781,11 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             for (; middle - done >= GRAPH_STEPS; done += GRAPH_STEPS) {
                 HIP_TRY(hipGraphLaunch(sl.graph_exec, e->stream));
                 sl.launches += per_replay;
+                if (turn) t_base += GRAPH_STEPS;
             }
         }
-        for (; done < middle; ++done) launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_LEARN | FLAG_SELECT, true);
-        launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_LEARN, true);  // learn(steps-1)
+        for (; done < middle; ++done) launch_step_any<T, Env>(e, sl, at_step(done), ev, base | FLAG_LEARN | FLAG_SELECT, true);
+        launch_step_any<T, Env>(e, sl, at_step(middle), ev, base | FLAG_LEARN, true);  // learn(steps-1)
     } else {
         // greedy evaluation: no table writes, hence no contention and no ordered path
         hipLaunchKernelGGL((k_eval<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK), 0,
@@ -937,6 +951,26 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         }
         st->device_clock_ms = clock_ms;
     }
+#ifdef QE_TURN_CLOCKS
+    if (sl.turn && getenv("QE_PRINT_TURN_CLOCKS")) {
+        static unsigned long long raw[512 * 8 * 8], clk[512 * 8];
+        (void)hipMemcpy(raw, sl.dbg, sizeof raw, hipMemcpyDeviceToHost);
+        (void)hipMemset(sl.dbg, 0, sizeof raw);
+        for (int k = 0; k < 512 * 8; ++k) { clk[k] = 0; for (int w = 0; w < 8; ++w) clk[k] = std::max(clk[k], raw[8 * k + w]); }
+        const char* names[8] = {"", "contested: classified", "last update starts", "last update issued", "last contested agent done",
+                                "last plain agent done", "first loads back", ""};
+        double sum[8] = {0}; long cnt[8] = {0};
+        for (int t = 40; t < 512 && t < sl.steps; ++t) {
+            const unsigned long long* r = clk + 8 * t;
+            if (!r[0]) continue;
+            const unsigned long long start = ~r[0];
+            for (int k = 1; k < 7; ++k) if (r[k]) { sum[k] += (double)(r[k] - start) * 10.0; ++cnt[k]; }
+        }
+        for (int k : {6, 1, 2, 3, 4, 5})
+            fprintf(stderr, "  [turn clocks] %-28s %8.0f ns after the first agent's start (mean over %ld steps)\n", names[k],
+                    cnt[k] ? sum[k] / cnt[k] : 0.0, cnt[k]);
+    }
+#endif
 #ifdef QE_STAMPS
     if (getenv("QE_PRINT_STAMPS")) {
         double seg[24];
@@ -1112,6 +1146,7 @@ int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_EVENT_TIMING && (value == 0 || value == 1)) { e->opt_timing = (int)value; return QE_OK; }
     if (option == QE_OPT_HOST_BLOCK && (value == 0 || value == 1)) { e->opt_host_block = (int)value; return QE_OK; }
     if (option == QE_OPT_LANE_ORDERED_PATH && value >= 0 && value <= 2) { e->opt_lane_ordered = (int)value; return QE_OK; }
+    if (option == QE_OPT_TURN_FORWARD && (value == 0 || value == 1)) { e->opt_turn_forward = (int)value; return QE_OK; }
     return fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 
@@ -1409,7 +1444,12 @@ int qe_env_create(qe_env** out, qe_engine* e, int64_t N, const qe_env_params* p)
     if (err == hipSuccess) err = env->term.ensure(un);
     if (err == hipSuccess) err = env->pred.ensure(un * 8);
     if (err == hipSuccess) err = env->aux.ensure(un);
+#ifdef QE_TURN_CLOCKS
+    if (err == hipSuccess) err = env->vinc.ensure(std::max<size_t>(un, 32768));
+    if (err == hipSuccess) err = hipMemset(env->vinc.p, 0, 32768 * sizeof(double));
+#else
     if (err == hipSuccess) err = env->vinc.ensure(un);
+#endif
     if (err == hipSuccess) err = env->bitmap.ensure((un + 31) / 32);
     if (err == hipSuccess) err = hipMemsetAsync(env->bitmap.p, 0, env->bitmap.cap * 4, e->stream);
     if (err == hipSuccess) err = env->adv_bitmap.ensure((un + 31) / 32);

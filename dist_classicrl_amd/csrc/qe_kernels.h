@@ -47,6 +47,7 @@ constexpr int FLAG_LIST_IN_LDS = 512;    // ordered path: the involved list (<= 
 constexpr int FLAG_PRESTAGED = 256;      // ordered path: the caller has staged the transitions in LDS (persistent kernel)
 constexpr int FLAG_VEC_INC_READY = 128;  // VEC, wide mode: the increments of the involved agents are already in vinc
 constexpr int FLAG_TURN = 1024;           // turnstile path: touches are registered on per-row lists (qe_step_turn.h)
+constexpr int FLAG_TURN_NO_FORWARD = 2048;  // turnstile path: always re-read written columns from the table (experiment switch)
 constexpr uint32_t TOK_INF = 0xFFFFFFFFu;
 constexpr unsigned ERR_EMPTY_CHOICE = 3u;  // Ctrl::error: a fused selection found no selectable action
 
@@ -59,7 +60,6 @@ struct Ctrl {
     unsigned long long involved_total;   // statistics: agents that reached the ordered path
     unsigned long long pending_total;    // statistics (wide mode, listed rounds): agents that entered the token rounds
     unsigned int pend_count[2];          // entries of the two pending lists of the current step
-    unsigned int blocks_done;            // turnstile path: workgroups of the current launch that have finished
 };
 
 struct DeltaEntry {
@@ -117,8 +117,11 @@ struct Ctx {
     int32_t* pend_list;     // N: agents that entered the token rounds of this step (wide mode at large N)
     // turnstile path (qe_step_turn.h; nullptr otherwise): `stamps` holds the list heads
     uint32_t* turn_next;    // [2][N][2] next node of the row list an agent is on (per parity and role)
-    uint32_t* turn_prog;    // [2][N][2] progress word of the row whose lowest toucher the agent is
+    unsigned long long* turn_prog;  // [2][N][2] progress word of the row whose lowest toucher the agent is
+                                    // {last value written to the row (fp32 tables) : 32 | writers done : 16 | readers done : 16}
     unsigned long long turn_epoch;  // tag of step 0 of this call (tags never repeat in an engine's life)
+    long long turn_t_off;   // turnstile path: this launch works on step ctrl->t_local + turn_t_off (a launch argument, so
+                            // that no launch has to count its finished workgroups to move the step counter)
     Ctrl* ctrl;
     // agent state: pending transition (s, a, pred, r, term) and current observation n
     int32_t* s;

@@ -33,6 +33,9 @@
 //
 // Every spin is bounded: after TURN_SPIN_LIMIT polls an agent gives up, raises ERR_TURN_TIMEOUT and all
 // later launches of the rollout return at once -- every wave exits whatever happens.
+//
+// The step index is ctrl->t_local + a launch argument (Ctx::turn_t_off): no launch ends with a count of its
+// finished workgroups (one more memory-side round trip on the critical path of every step).
 #pragma once
 
 namespace qe {
@@ -49,6 +52,10 @@ __device__ __forceinline__ uint32_t opaque_zero() {
 // value at the coherence point (returning atomic OR with zero)
 __device__ __forceinline__ uint32_t rmw_read(uint32_t* p) {
     return __hip_atomic_fetch_or(p, opaque_zero(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long rmw_read(unsigned long long* p) {
+    const unsigned long long z = opaque_zero();
+    return __hip_atomic_fetch_or(p, z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float rmw_read(float* p) {
     return __uint_as_float(rmw_read(reinterpret_cast<uint32_t*>(p)));
@@ -101,7 +108,7 @@ __device__ __forceinline__ void turn_push(const Ctx<T>& c, int64_t i, int64_t ro
     const unsigned long long old = atomicExch(&c.stamps[2 * row + par], ((unsigned long long)tag << 32) | link);
     const int64_t slot = turn_slot(c.N, par, i, role);
     c.turn_next[slot] = (uint32_t)(old >> 32) == tag ? (uint32_t)old : 0u;
-    c.turn_prog[slot] = 0u;
+    c.turn_prog[slot] = 0ull;
 }
 
 struct TurnWalk {
@@ -113,31 +120,44 @@ struct TurnWalk {
     unsigned long long cols_lower, cols_other;
 };
 
-// `h` = the row's list head, `own_next` = the walker's own link on this row (loaded early, coalesced)
-template <typename T>
-__device__ __forceinline__ TurnWalk turn_walk(const Ctx<T>& c, unsigned long long h, uint32_t own_next, int par,
-                                              uint32_t tag, int64_t i) {
-    TurnWalk w{0, 0, 0, 0, 0, 0ull, 0ull};
-    uint32_t link = (uint32_t)(h >> 32) == tag ? (uint32_t)h : 0u;
-    int64_t lowest = INT64_MAX;
-    // (a list holds every agent at most once: an agent pushes one node per row)
-    for (int64_t guard = 0; (link & 0xFFFFFFu) != 0u && guard <= c.N; ++guard) {
-        const uint32_t node = link & 0xFFFFFFu;
-        const int64_t j = (int64_t)((node - 1u) >> 1);
-        const int role = (int)((node - 1u) & 1u);
-        ++w.K;
-        w.writers += role;
-        if (role && j != i) {
-            const uint32_t col = link >> 24;
-            const unsigned long long bit = 1ull << (col < 63u ? col : 63u);
-            w.cols_other |= bit;
-            if (j < i) w.cols_lower |= bit;
-        }
-        if (j < i) { ++w.lower; w.lower_w += role; }
-        if (j < lowest) { lowest = j; w.prog = turn_slot(c.N, par, j, role); }
-        link = j == i ? own_next : c.turn_next[turn_slot(c.N, par, j, role)];
+// (a list holds every agent at most once: an agent pushes one node per row; `own_w` / `own_r` = the walker's own
+// links on the two rows, loaded early and coalesced)
+// One node of a walk: `link` is the node's entry, `j` / `role` its agent and role.
+__device__ __forceinline__ void turn_visit(TurnWalk& w, int64_t& lowest, uint32_t link, int64_t j, int role, int64_t i,
+                                           int64_t N, int par) {
+    ++w.K;
+    w.writers += role;
+    if (role && j != i) {
+        const uint32_t col = link >> 24;
+        const unsigned long long bit = 1ull << (col < 63u ? col : 63u);
+        w.cols_other |= bit;
+        if (j < i) w.cols_lower |= bit;
     }
-    return w;
+    if (j < i) { ++w.lower; w.lower_w += role; }
+    if (j < lowest) { lowest = j; w.prog = turn_slot(N, par, j, role); }
+}
+
+// The lists of the written row and of the read row walked side by side: the loads of the two next links are
+// in flight together (a walk is a chain of dependent loads; one after the other they cost their sum).
+template <typename T>
+__device__ __forceinline__ void turn_walk2(const Ctx<T>& c, unsigned long long head_s, uint32_t own_w,
+                                           unsigned long long head_n, uint32_t own_r, bool sep, int par, uint32_t tag,
+                                           int64_t i, TurnWalk& ws, TurnWalk& wn) {
+    uint32_t ls = (uint32_t)(head_s >> 32) == tag ? (uint32_t)head_s : 0u;
+    uint32_t ln = sep && (uint32_t)(head_n >> 32) == tag ? (uint32_t)head_n : 0u;
+    int64_t low_s = INT64_MAX, low_n = INT64_MAX;
+    for (int64_t guard = 0; ((ls | ln) & 0xFFFFFFu) != 0u && guard <= c.N; ++guard) {
+        const uint32_t node_s = ls & 0xFFFFFFu, node_n = ln & 0xFFFFFFu;
+        const int64_t js = (int64_t)((node_s - 1u) >> 1), jn = (int64_t)((node_n - 1u) >> 1);
+        const int role_s = (int)((node_s - 1u) & 1u), role_n = (int)((node_n - 1u) & 1u);
+        uint32_t nx_s = 0u, nx_n = 0u;
+        if (node_s) nx_s = js == i ? own_w : c.turn_next[turn_slot(c.N, par, js, role_s)];
+        if (node_n) nx_n = jn == i ? own_r : c.turn_next[turn_slot(c.N, par, jn, role_n)];
+        if (node_s) turn_visit(ws, low_s, ls, js, role_s, i, c.N, par);
+        if (node_n) turn_visit(wn, low_n, ln, jn, role_n, i, c.N, par);
+        ls = nx_s;
+        ln = nx_n;
+    }
 }
 
 // Coherent re-read of the columns in `cols` (see TurnWalk) of a row held in registers.
@@ -153,12 +173,56 @@ __device__ __forceinline__ void patch_row4_rmw(Row4<T>& r, T* q, int64_t row, in
         if ((m4 >> j) & 1u) r.v[j] = rmw_read(p + j);
 }
 
+// Value forwarding (fp32 tables): the upper half of a row's progress word carries the value its most recent
+// writer stored.  When every write that can have changed the row for the walker went to ONE column (the common
+// case: agents that share a state take the same greedy action), the poll that lets the walker proceed already
+// holds that column's current value and the coherent re-read of the table -- one more memory-side round trip
+// per link of a chain -- is dropped.
+template <typename T>
+struct TurnFwd { static constexpr bool on = false; };
+template <>
+struct TurnFwd<float> { static constexpr bool on = true; };
+__device__ __forceinline__ bool one_column(unsigned long long cols) {
+    return cols != 0ull && (cols & (cols - 1ull)) == 0ull && !(cols >> 63);  // (bit 63 stands for several actions)
+}
+template <typename T>
+__device__ __forceinline__ void set_col4(Row4<T>& r, int sub, int col, T v) {
+    if ((col >> 2) == sub) {
+        const int j = col & 3;
+        if (j == 0) r.v[0] = v; else if (j == 1) r.v[1] = v;
+        else if (j == 2) r.v[2] = v; else r.v[3] = v;
+    }
+}
+template <typename T>
+__device__ __forceinline__ T fwd_value(uint32_t bits) {
+    if constexpr (TurnFwd<T>::on) return __uint_as_float(bits);
+    else return T(0);
+}
+template <typename T>
+__device__ __forceinline__ uint32_t fwd_bits(T v) {
+    if constexpr (TurnFwd<T>::on) return __float_as_uint(v);
+    else return 0u;
+}
+
+// -DQE_TURN_CLOCKS (diagnostic build): where a launch spends its time -- per step (the first 512 of a call) the
+// latest 100 MHz clock at which any agent passed each point, in Ctx::vinc (printed with QE_PRINT_TURN_CLOCKS=1).
+#ifdef QE_TURN_CLOCKS
+// (one lane per wavefront and eight words per point: the clocks must not queue up on one address)
+#define TURN_CLK_PUT(k, v) do { if (t < 512) { const unsigned long long _m = __ballot(1); if ((int)__lane_id() == __ffsll((long long)_m) - 1) \
+    atomicMax(reinterpret_cast<unsigned long long*>(c.vinc) + (8 * t + (k)) * 8 + (blockIdx.x & 7), (v)); } } while (0)
+#define TURN_CLK(k) TURN_CLK_PUT(k, (unsigned long long)wall_clock64())
+#define TURN_CLK_START() TURN_CLK_PUT(0, ~(unsigned long long)wall_clock64())
+#else
+#define TURN_CLK(k) do {} while (0)
+#define TURN_CLK_START() do {} while (0)
+#endif
+
 template <typename T, class Env, int LC = 0>
 __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, int flags) {
     const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
     const int64_t i = gl >> c.lshift;
     const int sub = (int)(gl & (c.L - 1));
-    const long long t = c.ctrl->t_local;
+    const long long t = c.ctrl->t_local + c.turn_t_off;
     const bool dead = c.ctrl->error == ERR_TURN_TIMEOUT;  // an earlier launch gave up: do nothing
     if (i < c.N && !dead) {
         const int32_t n = c.n[i];
@@ -166,6 +230,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
             Row4<T> row = load_row4(c.q, n, c.ld, sub);
             advance_agent<T, Env, LC>(c, ev, i, sub, n, row, Env::valid4(ev, i, n, sub), t, flags);
         } else {
+            TURN_CLK_START();
             const int par = (int)(t & 1);
             const uint32_t tag = turn_tag(c.turn_epoch, t);
             const int32_t s = c.s[i];
@@ -181,9 +246,10 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
             const T pred = c.pred[i];
             const Hyper hyper = make_hyper(c, c.lr[t]);
             const uint32_t valid = Env::valid4(ev, i, n, sub);
-            const TurnWalk ws = turn_walk(c, head_s, own.y, par, tag, i);
-            TurnWalk wn{0, 0, 0, 0, 0, 0ull, 0ull};
-            if (sep) wn = turn_walk(c, head_n, own.x, par, tag, i);
+            TurnWalk ws{0, 0, 0, 0, 0, 0ull, 0ull}, wn{0, 0, 0, 0, 0, 0ull, 0ull};
+            if (head_s + head_n + own.x == 1ull) TURN_CLK(7);  // (never true: makes the clock below wait for the loads)
+            TURN_CLK(6);
+            turn_walk2(c, head_s, own.y, head_n, own.x, sep, par, tag, i, ws, wn);
             const bool cont_s = ws.K > 1;                        // I write s: any second toucher orders us
             const bool cont_n = sep && wn.K > 1 && wn.writers > 0;  // readers alone never conflict
             const int64_t cell = (int64_t)s * c.ld + a;
@@ -204,9 +270,11 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     else if (j == 2) row.v[2] = q1; else row.v[3] = q1;
                 }
                 if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
+                TURN_CLK(5);
             } else {
-                uint32_t* const prog_s = c.turn_prog + ws.prog;
-                uint32_t* const prog_n = c.turn_prog + wn.prog;
+                TURN_CLK(1);
+                unsigned long long* const prog_s = c.turn_prog + ws.prog;
+                unsigned long long* const prog_n = c.turn_prog + wn.prog;
                 const int W = LC ? LC : c.L;
                 {   // statistics: one atomic per wavefront, not one per agent on the same word
                     const unsigned long long mine = __ballot(sub == 0);
@@ -221,6 +289,17 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                 // writes in this step can differ from what I loaded at the start (coherent re-reads of those)
                 const TurnWalk& wr = sep ? wn : ws;
                 const unsigned long long cell_bit = 1ull << (a < 63 ? a : 63);
+                const bool fwd = TurnFwd<T>::on && !(flags & FLAG_TURN_NO_FORWARD);
+                // one column only: its current value arrives with the progress word (see TurnFwd)
+                const bool fwd_q0 = fwd && ws.cols_lower == cell_bit && a < 63;
+                const bool fwd_row = fwd && one_column(wr.cols_lower);
+                const unsigned long long cols_final = wr.cols_other | (sep ? 0ull : cell_bit);
+                const bool fwd_final = fwd && one_column(cols_final);
+                // Every writer of row s writes my column: nobody reads that cell from the table inside this launch
+                // (all of them take it from the progress word), so only the row's LAST writer stores it -- the
+                // others hand their value on with the progress word alone, and nobody waits for a table write.
+                const bool single_s = fwd && a < 63 && (ws.cols_other & ~cell_bit) == 0ull;
+                const bool last_w = ws.writers - ws.lower_w - 1 == 0;
                 int phase = 0;
                 for (int spin = 0; phase < 2; ++spin) {
                     if (spin >= TURN_SPIN_LIMIT) {  // never expected: give up, every later launch returns at once
@@ -229,30 +308,48 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     }
                     if (phase == 0) {
                         int ok = 1;
+                        uint32_t up_s = 0u, up_n = 0u;  // last value written to row s / row n (upper halves)
                         if (sub == 0) {
                             if (wait_s) {
-                                const uint32_t d = rmw_read(prog_s);
+                                const unsigned long long d64 = rmw_read(prog_s);
+                                const uint32_t d = (uint32_t)d64;
+                                up_s = (uint32_t)(d64 >> 32);
                                 ok &= (int)((d >> 16) + (d & 0xFFFFu)) == ws.lower;
                             }
-                            if (wait_n) ok &= (int)(rmw_read(prog_n) >> 16) == wn.lower_w;
+                            if (wait_n) {
+                                const unsigned long long d64 = rmw_read(prog_n);
+                                up_n = (uint32_t)(d64 >> 32);
+                                ok &= (int)((uint32_t)d64 >> 16) == wn.lower_w;
+                            }
                         }
                         if (wait_s || wait_n) ok = __shfl(ok, 0, W);
                         if (ok) {
+                            TURN_CLK(2);
                             T q0 = pred;  // = the table, unless a lower agent has written my cell in this step
-                            if (sub == 0 && (ws.cols_lower & cell_bit)) q0 = rmw_read(c.q + cell);
-                            patch_row4_rmw(row, c.q, n, c.ld, sub, wr.cols_lower);
+                            if (sub == 0 && (ws.cols_lower & cell_bit)) q0 = fwd_q0 ? fwd_value<T>(up_s) : rmw_read(c.q + cell);
+                            if (fwd_row) {
+                                const uint32_t up = __shfl(sep ? up_n : up_s, 0, W);
+                                set_col4(row, sub, __ffsll((long long)wr.cols_lower) - 1, fwd_value<T>(up));
+                            } else {
+                                patch_row4_rmw(row, c.q, n, c.ld, sub, wr.cols_lower);
+                            }
                             const T m = row_max_valid<LC>(row, valid, c.L);
                             T u;
                             const T q1 = Td<T>::apply(q0, r, m, term, hyper, c.mode, &u);
                             if (sub == 0) {
-                                const uint32_t done = rmw_write(c.q + cell, q1);
+                                uint32_t done = 0u;
+                                if (!single_s) done = rmw_write(c.q + cell, q1);
+                                else if (last_w) (void)rmw_write(c.q + cell, q1);  // (published by the kernel boundary)
                                 log_delta(c, t, i, cell, u);
                                 if (flags & FLAG_ACCOUNT) account(c, t, i, r, term);
-                                // the progress words move only after the exchange has returned (= is performed)
-                                const uint32_t one = 1u | (done & opaque_zero());
-                                if (cont_s) atomicAdd(prog_s, one << 16);
+                                // the progress words move only after the exchange has returned (= is performed);
+                                // writers of a row run one after the other, so the upper half is still what I polled
+                                // (zero when I am the row's lowest toucher) and one add replaces it by my value
+                                const unsigned long long one = 1ull | (unsigned long long)(done & opaque_zero());
+                                if (cont_s) atomicAdd(prog_s, ((unsigned long long)(uint32_t)(fwd_bits<T>(q1) - up_s) << 32) | (one << 16));
                                 if (cont_n) atomicAdd(prog_n, one);
                             }
+                            TURN_CLK(3);
                             if (later_w == 0) {
                                 // no later writer of the row: what I hold (+ my own write) is the row after step t
                                 if (!sep) {
@@ -273,11 +370,17 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     if (phase == 1) {
                         // select(t+1) reads Q[n] after every update of step t: all writers of row n done
                         int ok = 1;
-                        if (sub == 0) ok = (int)(rmw_read(sep ? prog_n : prog_s) >> 16) == (sep ? wn.writers : ws.writers);
+                        uint32_t up = 0u;
+                        if (sub == 0) {
+                            const unsigned long long d64 = rmw_read(sep ? prog_n : prog_s);
+                            up = (uint32_t)(d64 >> 32);
+                            ok = (int)((uint32_t)d64 >> 16) == (sep ? wn.writers : ws.writers);
+                        }
                         ok = __shfl(ok, 0, W);
                         if (ok) {
                             if (flags & FLAG_SELECT) {
-                                patch_row4_rmw(row, c.q, n, c.ld, sub, wr.cols_other | (sep ? 0ull : cell_bit));
+                                if (fwd_final) set_col4(row, sub, __ffsll((long long)cols_final) - 1, fwd_value<T>(__shfl(up, 0, W)));
+                                else patch_row4_rmw(row, c.q, n, c.ld, sub, cols_final);
                                 advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
                             }
                             phase = 2;
@@ -285,18 +388,15 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     }
                     if (phase < 2) __builtin_amdgcn_s_sleep(2);
                 }
+                TURN_CLK(4);
             }
         }
     }
-    // the last workgroup to finish moves the step counter (every workgroup has read it by then)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned prev = atomicAdd(&c.ctrl->blocks_done, 1u);
-        if (prev + 1u == gridDim.x) {
-            c.ctrl->blocks_done = 0u;
-            if ((flags & FLAG_LEARN) && !dead) c.ctrl->t_local = t + 1;
-        }
-    }
 }
+
+// Step counter of the turnstile path: the launches of a captured graph carry their offsets 0 .. G-1 as launch
+// arguments and the graph ends with this one-thread kernel (+G); eager launches carry the offset from the counter's
+// current value.
+__global__ void k_turn_bump(Ctrl* ctrl, long long by) { ctrl->t_local += by; }
 
 }  // namespace qe

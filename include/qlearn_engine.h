@@ -111,7 +111,10 @@ enum qe_option { QE_OPT_ROLLOUT_PATH = 0, QE_OPT_USE_GRAPH = 1 /* 1 (default): r
                                           word there; 0: stream synchronisation + copies */,
                  QE_OPT_LANE_ORDERED_PATH = 6 /* persistent kernel, up to 128 agents: 0 (default) = automatic, 1 = the build without the
                                                  general ordered path (steps with more than two touchers on a row are worked off one
-                                                 agent per round), 2 = the build with it */ };
+                                                 agent per round), 2 = the build with it */,
+                 QE_OPT_TURN_FORWARD = 7 /* turnstile path, fp32 tables: 1 (default) = a row's progress word carries the value its last
+                                            writer stored, successors whose view of the row can differ in that one column only take it
+                                            from their poll; 0 = they always re-read the table (measurement switch) */ };
 int qe_set_option(qe_engine* e, int32_t option, int64_t value);
 
 /* ---- Q-table I/O ----------------------------------------------------------------------------

@@ -225,7 +225,7 @@ def test_learn_vec_many_collisions_stay_exact():
 
 
 # ------------------------------------------------------------------------------- closed loop
-PATHS = ["stepwise", "persistent", "persistent_light", "wide", "wide_listed", "turnstile"]
+PATHS = ["stepwise", "persistent", "persistent_light", "wide", "wide_listed", "turnstile", "turnstile_reread"]
 
 
 def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="auto"):
@@ -240,6 +240,12 @@ def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="a
         path = "persistent"
     if path == "persistent" and (env.action_size > 64 or env.num_agents > 512):
         pytest.skip("more than 512 agents / 64 actions: the persistent kernel does not apply")
+    if path == "turnstile_reread":  # the turnstile path without value forwarding in the progress words
+        if mode != "iter" or dt != "f4":
+            pytest.skip("value forwarding exists for float32 learn_iter rollouts only: nothing to switch off")
+        from dist_classicrl_amd import _lib
+        algo.set_engine_option(_lib.OPT_TURN_FORWARD, 0)
+        path = "turnstile"
     if path == "turnstile" and mode != "iter":
         pytest.skip("learn_vec: the turnstile path orders learn_iter only (the engine would take its automatic choice)")
     if path == "wide_listed":  # the compacted-list rounds (automatic from 16384 agents), seven rounds
