@@ -293,13 +293,25 @@ __device__ __forceinline__ void advance_regs(const Ctx<T>& c, const EnvCtx& ev, 
 }
 
 // same, with the agent state kept in the global arrays (step-wise kernels)
+// (`aux` = c.aux[i], loaded by the caller: the turnstile kernel requests it with its first loads instead of
+// after its chain of row sharers, where it would be one more dependent round trip before the exit)
+template <typename T, class Env, int LC = 0>
+__device__ __forceinline__ void advance_agent(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
+                                              int32_t n, Row4<T>& row, uint32_t valid, long long t1,
+                                              int flags, uint32_t aux);
 template <typename T, class Env, int LC = 0>
 __device__ __forceinline__ void advance_agent(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
                                               int32_t n, Row4<T>& row, uint32_t valid, long long t1,
                                               int flags) {
+    advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t1, flags, c.aux[i]);
+}
+template <typename T, class Env, int LC>
+__device__ __forceinline__ void advance_agent(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
+                                              int32_t n, Row4<T>& row, uint32_t valid, long long t1,
+                                              int flags, uint32_t aux) {
     Pending<T> p;
     p.n = n;
-    p.aux = c.aux[i];
+    p.aux = aux;
     advance_regs<T, Env, LC>(c, ev, i, sub, row, valid, t1, flags, p);
     if (sub == 0) {
         c.s[i] = p.s; c.a[i] = p.a; c.pred[i] = p.pred; c.r[i] = p.r;

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
             const float r = c.r[i];
             const bool term = c.term[i] != 0;
             const T pred = c.pred[i];
+            const uint32_t aux0 = c.aux[i];  // (for the selection of step t+1 at the end)
             const Hyper hyper = make_hyper(c, c.lr[t]);
             const uint32_t valid = Env::valid4(ev, i, n, sub);
             TurnWalk ws{0, 0, 0, 0, 0, 0ull, 0ull}, wn{0, 0, 0, 0, 0, 0ull, 0ull};
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     if (j == 0) row.v[0] = q1; else if (j == 1) row.v[1] = q1;
                     else if (j == 2) row.v[2] = q1; else row.v[3] = q1;
                 }
-                if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
+                if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
                 TURN_CLK(5);
             } else {
                 TURN_CLK(1);
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                                         else if (j == 2) row.v[2] = mine; else row.v[3] = mine;
                                     }
                                 }
-                                if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
+                                if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
                                 phase = 2;
                             } else {
                                 phase = 1;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                             if (flags & FLAG_SELECT) {
                                 if (fwd_final) set_col4(row, sub, __ffsll((long long)cols_final) - 1, fwd_value<T>(__shfl(up, 0, W)));
                                 else patch_row4_rmw(row, c.q, n, c.ld, sub, cols_final);
-                                advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags);
+                                advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
                             }
                             phase = 2;
                         }
