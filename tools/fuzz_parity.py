@@ -11,7 +11,7 @@ import test_gpu_parity as tp
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-only_path = sys.argv[3] if len(sys.argv) > 3 else None  # e.g. "turnstile": every case through that path
+only_path = sys.argv[3] if len(sys.argv) > 3 else None  # e.g. "turnstile" / "turnstile_reread": every case through that path
 t_end = time.time() + budget
 n_ok = n_bad = n_skip = n_div = 0
 t_note = time.time()
