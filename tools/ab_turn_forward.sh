@@ -1,6 +1,8 @@
 #!/usr/bin/env bash
 # Turnstile path: parity cases, then bench lines with / without value forwarding (results are identical; timing switch),
 # then -- if a -DQE_TURN_CLOCKS build of the engine lies at tools/libqe_turn_clocks.so -- where a launch spends its time.
+# That build (in the container, before gpurun):  bash dist_classicrl_amd/csrc/build.sh -DQE_TURN_CLOCKS -o ../../tools/libqe_turn_clocks.so
+# (the later -o wins; *.so files are git-ignored but travel to the GPU box).
 set -e
 mkdir -p gpurun_out
 timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "turnstile" > gpurun_out/fwd_parity.log 2>&1 || { tail -30 gpurun_out/fwd_parity.log; exit 1; }
