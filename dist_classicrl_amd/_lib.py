@@ -17,6 +17,7 @@ import os
 # QE_LIB_PATH lets a developer A/B two builds of the library in one session; default = in-tree build
 LIB_PATH = Path(os.environ.get("QE_LIB_PATH") or Path(__file__).resolve().parent / "csrc" / "libqlearn_engine.so")
 
+ABI_VERSION = 2  # QE_ABI_VERSION of include/qlearn_engine.h
 QE_F32, QE_F64 = 0, 1
 LEARN_ITER, LEARN_VEC = 0, 1
 ENV_HASH, ENV_GRID, ENV_BANDIT, ENV_TICTACTOE = 0, 1, 2, 3
@@ -31,6 +32,16 @@ OPT_TURN_FORWARD = 7
 PATH_AUTO, PATH_STEPWISE, PATH_PERSISTENT, PATH_WIDE, PATH_TURNSTILE = 0, 1, 2, 3, 4
 
 ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INDEX = -1, -2, -3, -4, -5
+
+
+def decode_variant(v: int) -> dict:
+    """Fields of ``qe_rollout_stats.kernel_variant`` (include/qlearn_engine.h)."""
+    v = int(v)
+    return {
+        "path": {1: "stepwise", 2: "persistent", 3: "wide", 4: "turnstile", 5: "eval"}.get(v & 15, "none"),
+        "lean": (v >> 4) & 3, "help": bool((v >> 6) & 1), "full": bool((v >> 7) & 1), "light": bool((v >> 8) & 1),
+        "cap512": bool((v >> 9) & 1), "nv": (v >> 12) & 255, "masked": bool((v >> 20) & 1),
+    }
 
 
 class EngineError(RuntimeError):
@@ -63,6 +74,8 @@ class RolloutStats(C.Structure):
         ("device_clock_ms", C.c_double),
         ("host_begin_us", C.c_double),
         ("host_end_us", C.c_double),
+        ("kernel_variant", C.c_int64),
+        ("complex_steps", C.c_int64),
     ]
 
 
@@ -147,8 +160,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table diverge
         fn.restype = res
         fn.argtypes = args
-    if lib.qe_abi_version() != 1:
-        msg = f"ABI version mismatch: library {lib.qe_abi_version()}, binding 1"
+    if lib.qe_abi_version() != ABI_VERSION:
+        msg = f"ABI version mismatch: library {lib.qe_abi_version()}, binding {ABI_VERSION}"
         raise ImportError(msg)
     _lib = lib
     return lib

@@ -138,6 +138,7 @@ class GpuRolloutQLearning(BaseRuntime):
             ep_steps.append(step_idx)
         for f in total:
             total[f] += getattr(st, f)
+        self._variants.add(int(st.kernel_variant))
 
     def _rollout(self, env, steps, learn):
         lib = _lib.load()
@@ -147,8 +148,9 @@ class GpuRolloutQLearning(BaseRuntime):
         mode = _lib.LEARN_ITER if self.learn_mode == "iter" else _lib.LEARN_VEC
         total = {"kernel_ms": 0.0, "launches": 0, "episodes": 0, "involved": 0, "episodes_dropped": 0,
                  "dominant_ms": 0.0, "dominant_launches": 0, "dominant_env_steps": 0, "device_clock_ms": 0.0,
-                 "host_begin_us": 0.0, "host_end_us": 0.0}
+                 "host_begin_us": 0.0, "host_end_us": 0.0, "complex_steps": 0}
         history, ep_steps, traces = [], [], []
+        self._variants = set()  # kernel builds the launches of this call ran (qe_rollout_stats.kernel_variant)
         chunk_max = max(1, int(lib.qe_rollout_chunk_limit(algo.handle, env.handle, 1 if learn else 0)))
         sync = self.delta_sync if learn else None
         collect_trace = self.trace_actions is not None and self.trace_actions is not False
@@ -235,6 +237,8 @@ class GpuRolloutQLearning(BaseRuntime):
                 self._since_sync = logged[0]
                 if any(exchanges):
                     sync.flush()  # the exchange still in flight is completed (remote deltas applied) before returning
+        total["kernel_variant"] = max(self._variants) if self._variants else 0
+        total["kernel_variants"] = sorted(self._variants)
         self.last_stats = total
         if traces:
             self.last_trace = np.concatenate(traces)
@@ -271,6 +275,7 @@ class GpuRolloutQLearning(BaseRuntime):
             rets = np.empty(cnt, dtype=np.float32)
             lib.qe_episode_log(algo.handle, cnt, None, None, _lib.ptr(rets, C.c_float))
         self.last_stats = {f: getattr(st, f) for f, _ in st._fields_}
+        self.last_stats["kernel_variants"] = [int(st.kernel_variant)]
         obs, aux, rewards = state[:n].view(np.int32), state[n:2 * n], state[2 * n:].view(np.float32)
         total = np.float32(self._fused_sum.value) if cnt else 0  # (0 / 0 -> ZeroDivisionError, like the reference)
         return rets, total, env.adopt_state(obs, rewards, aux)

@@ -1,10 +1,7 @@
 #!/usr/bin/env bash
-# Build libqlearn_engine.so for gfx950 in-tree (cross-compiles without a GPU).
-# -ffp-contract=off: TD arithmetic must round exactly like the reference (qe_device.h, Td<>).
+# Build libqlearn_engine.so for gfx950 in-tree (cross-compiles without a GPU): see Makefile.
+# Extra compiler flags (diagnostic builds, e.g. -DQE_STAMPS) go through EXTRA="..." and need OBJ=<other dir>.
 set -euo pipefail
 cd "$(dirname "$0")"
-HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
-    -Wall -Wno-unused-function -Wno-unused-result -Wno-pass-failed \
-    qe_engine.hip -o libqlearn_engine.so "$@"
-echo "built $(pwd)/libqlearn_engine.so"
+make -j"${JOBS:-8}" "$@"
+echo "built $(pwd)/${LIB:-libqlearn_engine.so}"

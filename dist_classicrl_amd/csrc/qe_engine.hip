@@ -1,30 +1,14 @@
 // qe_engine.hip -- host side of libqlearn_engine.so: owns the HBM-resident Q-table and agent
 // state, launches the gfx950 kernels of qe_kernels.h, exports the C ABI of include/qlearn_engine.h.
-#include "../../include/qlearn_engine.h"
-
-#include <time.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <type_traits>
-#include <vector>
-
-#include "qe_kernels.h"
-#include "qe_rollout_lane.h"
-#include "qe_step_turn.h"
-
-using namespace qe;
+// (The rollout kernels are instantiated in qe_inst_lane.hip / qe_inst_step.hip, one object per table dtype and
+// environment; this file holds everything that is not templated on them.)
+#include "qe_host.h"
 
 namespace {
-
 thread_local std::string g_err;
+}
 
-int fail(int code, const char* fmt, ...) {
+int qe_fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -34,56 +18,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess)                                                                \
-            return fail(_e == hipErrorOutOfMemory ? QE_ERR_OOM : QE_ERR_NO_DEVICE,           \
-                        "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e),    \
-                        __FILE__, __LINE__, #expr);                                          \
-    } while (0)
-
-template <typename U>
-struct DevBuf {
-    U* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = std::max(n, (size_t)256);
-        hipError_t e = hipMalloc((void**)&p, want * sizeof(U));
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-template <typename U>
-struct PinnedBuf {  // page-locked host staging: async copies without a host-side temporary
-    U* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        const size_t want = std::max(n + n / 2, (size_t)1024);
-        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(U), hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
+namespace {
 
 // Episode-log entries by key = (step << 32 | agent): the append order of base_runtime.py:218-221.
 // Keys are unique; large logs (tens of thousands of episodes per chunk at many agents) take an LSD
@@ -132,209 +67,7 @@ int lanes_per_row(int ld) {  // smallest power of two L with 4*L >= ld
 
 }  // namespace
 
-constexpr int MAX_TOKEN_ROUNDS = 24;   // chip-wide rounds before the single-workgroup clean-up (wide mode)
-constexpr int64_t LISTED_MIN_AGENTS = 16384;  // from here on the rounds walk compacted lists
-constexpr int LISTED_MIN_ROUNDS = 6;   // ... and only when at least this many rounds run
-constexpr int LISTED_RECOMPACT = 3;    // rounds on the first list before the second compaction
-constexpr unsigned LISTED_GRID = 1024; // blocks of a listed round (grid-stride)
-constexpr long long HOST_LOG_CAP = 1 << 18;  // episode-log entries of a slot's host result block (persistent path)
-
-// Everything one in-flight rollout owns, so that the next rollout can be enqueued before the results
-// of the previous one are read back.
-struct RolloutSlot {
-    Ctrl* ctrl = nullptr;
-    DevBuf<unsigned long long> thr, ep_key, ep_key_packed;
-    DevBuf<double> lr;
-    DevBuf<float> ep_ret, ep_ret_packed;
-    PinnedBuf<unsigned long long> h_thr, h_key;
-    PinnedBuf<double> h_lr;
-    PinnedBuf<float> h_ret;
-    PinnedBuf<Ctrl> h_ctrl;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, sched_ready = nullptr;
-    std::vector<hipEvent_t> sample_ev;  // event pairs around sampled dominant-kernel launches
-    bool busy = false, persistent = false, wide = false, turn = false, timed = true;
-    int n_samples = 0;
-    int64_t steps = 0, N = 0, launches = 0;
-    int32_t* trace_host = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int rounds = 4;  // token rounds per step of this call (wide mode)
-    int64_t plan_offset = -1;  // >= 0: schedules come from the engine's plan at this offset
-    double* dbg = nullptr;  // env->vinc of the rollout in flight (diagnostic builds)
-    // Host result block (persistent path): page-locked, host-coherent memory the rollout kernel writes
-    // itself -- control words, final observations / env state / running returns, episode log -- so that
-    // qe_rollout_end neither synchronises a stream nor issues a copy: it spins on hb->seq.
-    HostBlock* hb = nullptr;
-    int32_t* hb_obs = nullptr;
-    uint32_t* hb_aux = nullptr;
-    float* hb_acc = nullptr;
-    unsigned long long* hb_key = nullptr;
-    float* hb_ret = nullptr;
-    size_t hb_agents = 0;
-    unsigned long long seq = 0;  // value hb->seq takes when the rollout in flight has published
-    bool fast = false;           // the rollout in flight publishes through the host block
-    bool inline_sched = false;   // ... and carries its schedule values in its kernel arguments
-    InlineSched sched{};
-    struct qe_env* env = nullptr;  // environment of the rollout in flight
-    void release() {
-        if (ctrl) (void)hipFree(ctrl);
-        ctrl = nullptr;
-        for (void* h : {(void*)hb, (void*)hb_obs, (void*)hb_aux, (void*)hb_acc, (void*)hb_key, (void*)hb_ret})
-            if (h) (void)hipHostFree(h);
-        hb = nullptr; hb_obs = nullptr; hb_aux = nullptr; hb_acc = nullptr; hb_key = nullptr; hb_ret = nullptr;
-        hb_agents = 0;
-        thr.release(); ep_key.release(); lr.release(); ep_ret.release();
-        ep_key_packed.release(); ep_ret_packed.release();
-        h_thr.release(); h_key.release(); h_lr.release(); h_ret.release(); h_ctrl.release();
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (sched_ready) (void)hipEventDestroy(sched_ready);
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        graph_exec = nullptr;
-        for (hipEvent_t x : sample_ev) (void)hipEventDestroy(x);
-        sample_ev.clear();
-        ev0 = ev1 = sched_ready = nullptr;
-    }
-};
-
-struct qe_replay;
-
-struct qe_engine {
-    qe_replay* replay = nullptr;  // ring the fused rollouts push their transitions into (qe_replay_attach)
-    int device = 0;
-    int dtype = QE_F32;
-    int64_t S = 0;
-    int32_t A = 0, ld = 0, L = 1, lshift = 0;
-    double gamma = 0.97;
-    uint64_t seed = 0, step_ctr = 0;
-    double wall_clock_khz = 100000.0;  // rate of wall_clock64() (s_memrealtime), ticks per millisecond
-    uint32_t agent_offset = 0;
-    int num_cus = 64;
-    int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
-    unsigned long long turn_epoch = 1;  // turnstile path: list tag of the next call's step 0 (0 = the touch counters' rest value)
-    bool stamps_hold_lists = false;     // the touch-counter array holds turnstile list heads (cleared before counters use it)
-    int turn_blocks_per_cu = 0;         // resident workgroups per CU the turnstile kernels are dispatched for (0: not yet queried)
-    int opt_graph = 1; // QE_OPT_USE_GRAPH
-    int opt_rounds = 0; // QE_OPT_TOKEN_ROUNDS (0 = automatic)
-    int auto_rounds = 4; // wide mode: rounds chosen from the previous call's statistics
-    int64_t listed_min = LISTED_MIN_AGENTS;  // QE_OPT_LISTED_MIN_AGENTS
-    int opt_timing = 1;  // QE_OPT_EVENT_TIMING: bracket rollouts with HIP events (persistent path: off = in-kernel clock only)
-    int opt_host_block = 1;  // QE_OPT_HOST_BLOCK: persistent rollouts publish through the host result block
-    int opt_turn_forward = 1;  // QE_OPT_TURN_FORWARD: value forwarding in the progress words of the turnstile path
-    int opt_lane_ordered = 0;  // QE_OPT_LANE_ORDERED_PATH: 0 = automatic, 1 = light build (sequential fallback), 2 = full build
-    int lane_light = -1;       // automatic choice for the next launch (-1: not decided yet)
-    unsigned long long seq_ctr = 0;
-    double host_begin_us = 0.0;  // diagnostics (QE_PRINT_HOST)
-    hipStream_t stream = nullptr;
-    bool own_stream = true;
-    void* q = nullptr;
-    unsigned long long* stamps = nullptr;
-    Ctrl* ctrl = nullptr;
-    uint32_t* tok = nullptr;  // [2][S] wide-mode tokens, allocated on first use, all TOK_INF at rest
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // schedules
-    DevBuf<unsigned long long> thr;
-    DevBuf<double> lr;
-    // batch-API scratch (qe_choose_actions / qe_learn / qe_table_cells)
-    DevBuf<int32_t> b_s, b_a, b_n, b_out, b_list;
-    DevBuf<float> b_r, b_acc;
-    DevBuf<uint8_t> b_term, b_pred;
-    DevBuf<uint32_t> b_aux, b_mask, b_bitmap;
-    DevBuf<double> b_vals, b_vinc;
-    // episode log
-    DevBuf<unsigned long long> ep_key;
-    DevBuf<float> ep_ret;
-    long long ep_cap = 1 << 22;
-    std::vector<std::pair<unsigned long long, float>> ep_host, ep_tmp;
-    // delta log (caller-owned buffer)
-    DeltaEntry* dlog = nullptr;
-    long long dlog_cap = 0, dlog_count = 0;
-    DevBuf<int32_t> trace;
-    // schedule plan (qe_schedule_plan): values of a whole training call, consumed by the rollouts
-    DevBuf<unsigned long long> plan_thr;
-    DevBuf<double> plan_lr;
-    PinnedBuf<unsigned long long> h_plan_thr;
-    PinnedBuf<double> h_plan_lr;
-    int64_t plan_count = 0, plan_cursor = 0;
-    unsigned timing_skip = 0;      // launches since the engine was created (timed-launch cadence)
-    double ms_per_step_est = 0.0;  // device time per step of the last timed launch
-    hipEvent_t plan_ready = nullptr;
-    PinnedBuf<uint8_t> h_stage;         // page-locked staging of the unfused batch API (one call at a time)
-    DevBuf<uint8_t> warm_scratch;       // 1 MB of device memory for warm_pinned()
-    hipStream_t copy_stream = nullptr;  // result read-back beside the compute stream
-    RolloutSlot slots[2];               // two rollouts may be in flight (begin k+1 before end k)
-    size_t esize() const { return dtype == QE_F32 ? 4 : 8; }
-};
-
-struct qe_replay {
-    int device = 0;
-    int64_t capacity = 0, position = 0;
-    bool full = false;
-    DevBuf<int64_t> s, a, n, idx, o_s, o_a, o_n;
-    DevBuf<double> r, o_r;
-    DevBuf<uint8_t> d, o_d;
-    DevBuf<unsigned> bad;
-    hipStream_t stream = nullptr;
-    qe_engine* attached = nullptr;  // engine whose fused rollouts push into this ring
-};
-
-struct qe_env {
-    qe_engine* e = nullptr;
-    qe_env_params p{};
-    int64_t N = 0;
-    DevBuf<int32_t> s, a, n, list, pend_list;
-    DevBuf<float> r, acc;
-    DevBuf<uint8_t> term, pred, masks;
-    DevBuf<uint32_t> aux, bitmap, adv_bitmap;
-    DevBuf<uint32_t> turn_next;            // turnstile path: [2][N][2], allocated on first use
-    DevBuf<unsigned long long> turn_prog;  // turnstile path: [2][N][2] progress words
-    DevBuf<double> vinc;
-    // host copy of (observations, env-internal state, running returns) left by the latest rollout's
-    // result block; valid until anything else changes the device state
-    const int32_t* mirror_obs = nullptr;
-    const uint32_t* mirror_aux = nullptr;
-    const float* mirror_acc = nullptr;
-};
-
 namespace {
-
-EnvCtx make_envctx(const qe_engine* e, const qe_env_params* p, const uint32_t* maskbits, int masked) {
-    EnvCtx ev{};
-    ev.S = e->S;
-    ev.A = e->A;
-    ev.n_words = (e->A + 31) / 32;
-    ev.maskbits = maskbits;
-    if (p) {
-        ev.kind = p->kind; ev.masked = p->masked; ev.seed = p->seed; ev.p_term_256 = p->p_term_256;
-        ev.side = p->side; ev.episode_len = p->episode_len; ev.agent_offset = p->agent_offset;
-    } else {
-        ev.kind = -1; ev.masked = masked;
-    }
-    return ev;
-}
-
-template <typename T>
-Ctx<T> base_ctx(qe_engine* e, int64_t N) {
-    Ctx<T> c{};
-    c.q = (T*)e->q; c.S = e->S; c.A = e->A; c.ld = e->ld; c.L = e->L; c.lshift = e->lshift;
-    c.N = N; c.stamps = e->stamps; c.ctrl = e->ctrl;
-    c.thr = (const QE_AS4 unsigned long long*)e->thr.p; c.lr = (const QE_AS4 double*)e->lr.p;
-    c.seed_lo = (uint32_t)e->seed; c.seed_hi = (uint32_t)(e->seed >> 32);
-    c.agent_offset = e->agent_offset; c.step0 = e->step_ctr; c.gamma = e->gamma;
-    c.ep_key = e->ep_key.p; c.ep_ret = e->ep_ret.p; c.ep_cap = e->ep_cap;
-    return c;
-}
-
-template <typename T>
-Ctx<T> env_ctx(qe_engine* e, qe_env* env) {
-    Ctx<T> c = base_ctx<T>(e, env->N);
-    c.s = env->s.p; c.a = env->a.p; c.n = env->n.p; c.r = env->r.p; c.term = env->term.p;
-    c.pred = (T*)env->pred.p; c.aux = env->aux.p; c.acc = env->acc.p;
-    c.inv_bitmap = env->bitmap.p; c.inv_list = env->list.p; c.vinc = env->vinc.p;
-    c.agent_offset = env->p.agent_offset;
-    return c;
-}
-
-inline unsigned grid_for(int64_t threads, int block) { return (unsigned)((threads + block - 1) / block); }
 
 unsigned long long eps_threshold(double eps) {
     if (!(eps > 0.0)) return 0ull;
@@ -393,29 +126,6 @@ static int slot_host_block(qe_engine* e, RolloutSlot& sl, size_t agents) {
         sl.hb_agents = want;
     }
     return QE_OK;
-}
-
-// Turnstile path (qe_step_turn.h): its workgroups wait for each other inside the launch, so all of them
-// must be resident -- FAST_BLOCK threads each, TURN_BLOCKS_PER_CU per CU asked for (the kernels need
-// <= 128 registers: four workgroups of four wavefronts fit a CU) -- and the progress counts are 16 bits.
-constexpr int TURN_BLOCKS_PER_CU = 2;
-constexpr bool TURN_AUTO = true;  // automatic choice for agent counts above the persistent kernel's
-static bool turn_fits(const qe_engine* e, int64_t N) {
-    const int64_t blocks = (N * e->L + FAST_BLOCK - 1) / FAST_BLOCK;
-    return N <= 60000 && blocks <= (int64_t)e->num_cus * TURN_BLOCKS_PER_CU && e->ld <= 256;
-}
-// The touch-counter array doubles as the turnstile path's list heads; the counters' kernels expect zeros.
-static int stamps_as_counters(qe_engine* e) {
-    if (e->stamps_hold_lists) {
-        HIP_TRY(hipMemsetAsync(e->stamps, 0, (size_t)e->S * 2 * sizeof(unsigned long long), e->stream));
-        e->stamps_hold_lists = false;
-    }
-    return QE_OK;
-}
-
-// one launch per rollout on one CU, one agent per lane with its whole row in registers (qe_rollout_lane.h)
-static bool persistent_path(const qe_engine* e, const qe_env* env, int learn) {
-    return learn && env->N <= LANE_MAX_AGENTS && e->ld <= 64 && (e->opt_path == 0 || e->opt_path == 2);
 }
 
 // Room for a schedule plan of `count` steps (page-locked staging + device copy): sized generously and doubled
@@ -484,106 +194,6 @@ void pack_masks(const uint8_t* masks, int64_t n, int A, std::vector<uint32_t>& o
             if (masks[i * A + j]) out[(size_t)i * nw + (j >> 5)] |= 1u << (j & 31);
 }
 
-constexpr int MAX_SAMPLES = 256;
-
-constexpr int GRAPH_STEPS = 50;  // vector steps per captured graph (step-wise / wide paths)
-
-template <typename T, class Env, int LC = 0>
-void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow,
-                 int sample = -1) {
-    const dim3 grid(grid_for(c.N * c.L, FAST_BLOCK)), block(FAST_BLOCK);
-    if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample], e->stream);
-    if (c.turn_next) {  // turnstile path: the whole vector step is this one launch (qe_step_turn.h)
-        hipLaunchKernelGGL((k_step_turn<T, Env, LC>), grid, block, 0, e->stream, c, ev,
-                           flags | FLAG_TURN | (e->opt_turn_forward ? 0 : FLAG_TURN_NO_FORWARD));
-        if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
-        ++sl.launches;
-        return;
-    }
-    hipLaunchKernelGGL((k_step_fast<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags);
-    if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
-    ++sl.launches;
-    if (!slow) return;
-    if (c.tok && c.mode == QE_LEARN_VEC) {
-        // wide mode, learn_vec: increments of all involved agents from the pre-step table, then rounds that
-        // add them row by row in agent order, the one-workgroup clean-up, postponed selections
-        const int rounds = sl.rounds;
-        const dim3 cgrid(grid_for((c.N + 31) / 32, FAST_BLOCK));
-        const dim3 lgrid(std::min<unsigned>(grid.x, LISTED_GRID));
-        const int32_t* list0 = c.pend_list;  // nullptr: scan the bitmap
-        int launches = 3;
-        if (list0) {
-            hipLaunchKernelGGL((k_compact<T>), cgrid, block, 0, e->stream, c, (const uint32_t*)c.inv_bitmap, c.pend_list, 0);
-            ++launches;
-        }
-        hipLaunchKernelGGL((k_vec_inc<T, Env, LC>), list0 ? lgrid : grid, block, 0, e->stream, c, ev, list0);
-        for (int r = 0; r < rounds; ++r) {
-            if (list0 && r == LISTED_RECOMPACT) {
-                hipLaunchKernelGGL((k_compact<T>), cgrid, block, 0, e->stream, c, (const uint32_t*)c.inv_bitmap, c.inv_list, 1);
-                ++launches;
-            }
-            const bool second = list0 && r >= LISTED_RECOMPACT;
-            hipLaunchKernelGGL((k_vec_round<T>), lgrid, block, 0, e->stream, c, flags, r,
-                               (const int32_t*)(second ? c.inv_list : list0), second ? 1 : 0);
-        }
-        hipLaunchKernelGGL((k_step_slow<T, Env, LC>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev,
-                           (flags & ~FLAG_SELECT) | FLAG_VEC_INC_READY);
-        if (list0)
-            hipLaunchKernelGGL((k_advance_list<T, Env, LC>), lgrid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1, list0);
-        else
-            hipLaunchKernelGGL((k_advance<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1);
-        sl.launches += rounds + launches;
-        return;
-    }
-    if (c.tok) {  // wide mode: token rounds on the whole chip, clean-up, postponed selections
-        const int rounds = sl.rounds;
-        if (c.pend_list) {
-            const dim3 cgrid(grid_for((c.N + 31) / 32, FAST_BLOCK));
-            const dim3 lgrid(std::min<unsigned>(grid.x, LISTED_GRID));
-            hipLaunchKernelGGL((k_compact<T>), cgrid, block, 0, e->stream, c, (const uint32_t*)c.inv_bitmap, c.pend_list, 0);
-            int launches = 3;
-            for (int r = 0; r < rounds; ++r) {
-                if (r == LISTED_RECOMPACT) {
-                    hipLaunchKernelGGL((k_compact<T>), cgrid, block, 0, e->stream, c, (const uint32_t*)c.inv_bitmap, c.inv_list, 1);
-                    ++launches;
-                }
-                const bool second = r >= LISTED_RECOMPACT;
-                hipLaunchKernelGGL((k_token_round_list<T, Env, LC>), lgrid, block, 0, e->stream, c, ev, flags, r,
-                                   (const int32_t*)(second ? c.inv_list : c.pend_list), second ? 1 : 0);
-            }
-            hipLaunchKernelGGL((k_step_slow<T, Env, LC>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
-            hipLaunchKernelGGL((k_advance_list<T, Env, LC>), lgrid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1,
-                               (const int32_t*)c.pend_list);
-            sl.launches += rounds + launches;
-            return;
-        }
-        for (int r = 0; r < rounds; ++r)
-            hipLaunchKernelGGL((k_token_round<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags, r);
-        hipLaunchKernelGGL((k_step_slow<T, Env, LC>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags & ~FLAG_SELECT);
-        hipLaunchKernelGGL((k_advance<T, Env, LC>), grid, block, 0, e->stream, c, ev, flags | FLAG_T_MINUS_1);
-        sl.launches += rounds + 2;
-        return;
-    }
-    hipLaunchKernelGGL((k_step_slow<T, Env, LC>), dim3(1), dim3(SLOW_BLOCK), 0, e->stream, c, ev, flags);
-    ++sl.launches;
-}
-
-// Lane-group widths of the BASELINE shapes get kernels with compile-time width (DPP lane exchange
-// instead of ds_bpermute); everything else runs the generic build.
-template <typename T, class Env>
-void launch_step_any(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int flags, bool slow,
-                     int sample = -1) {
-    if constexpr (std::is_same<Env, HashEnv>::value) {
-        switch (c.L) {
-            case 4: return launch_step<T, Env, 4>(e, sl, c, ev, flags, slow, sample);
-            case 8: return launch_step<T, Env, 8>(e, sl, c, ev, flags, slow, sample);
-            case 16: return launch_step<T, Env, 16>(e, sl, c, ev, flags, slow, sample);
-            default: break;
-        }
-    }
-    launch_step<T, Env, 0>(e, sl, c, ev, flags, slow, sample);
-}
-
 // Enqueue one rollout (no host synchronisation): schedules, control block, kernels, events.
 template <typename T, class Env>
 int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps, int mode, int learn,
@@ -615,7 +225,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     }
     const bool persistent = persistent_path(e, env, learn);
     if (learn && e->opt_path == 2 && !persistent)
-        return fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and action_size <= 64 (have %lld agents, %d actions)",
+        return qe_fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and action_size <= 64 (have %lld agents, %d actions)",
                     (long long)env->N, (int)e->A);
     // turnstile path: one launch per step, all workgroups resident, rows handed from agent to agent
     const bool turn = learn && !persistent && mode == QE_LEARN_ITER && turn_fits(e, env->N) &&
@@ -674,123 +284,12 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
     if (sl.fast && !e->opt_timing) sl.timed = false;  // in-kernel clock only
     if (sl.timed) HIP_TRY(hipEventRecord(sl.ev0, e->stream));
     if (persistent) {
-        const unsigned block = (unsigned)((env->N + 63) / 64 * 64);
-#ifdef QE_EXPERIMENT
-        const int FLAG_ACCOUNT_X = FLAG_ACCOUNT | (getenv("QE_DEBUG_FLAGS") ? atoi(getenv("QE_DEBUG_FLAGS")) << 20 : 0);
-#define FLAG_ACCOUNT FLAG_ACCOUNT_X
-#endif
-        const bool lean = mode == QE_LEARN_ITER && !c.trace && !c.rp.s;
-        auto go = [&](auto nv, auto masked) {
-            constexpr int NV = decltype(nv)::value;
-            constexpr bool MK = decltype(masked)::value;
-            // the BASELINE shapes with up to 128 agents (two wavefronts) get builds that know they are plain
-            // training rollouts (LEAN, see the kernel) and may use the whole register file
-            constexpr bool HAS_LEAN = std::is_same<T, float>::value &&
-                                      ((std::is_same<Env, HashEnv>::value && !MK && (NV == 2 || NV == 4)) ||
-                                       std::is_same<Env, TttEnv>::value);
-            const bool full = (int64_t)block == env->N;  // every lane of the agents' wavefronts holds an agent
-            // The build without the general ordered path (SEQ, see the kernel) where steps with more than two
-            // touchers on a row are rare: expected from the shape at first (agents^2 / states), from the
-            // previous launch's count afterwards.
-            if (e->lane_light < 0) e->lane_light = (double)env->N * (double)env->N < 0.1 * (double)e->S ? 1 : 0;
-            const bool light = e->opt_lane_ordered == 1 || (e->opt_lane_ordered == 0 && e->lane_light == 1);
-            // (no wavefronts beyond the agents' and the draw producers': the others only serve the general ordered path)
-            if (HAS_LEAN && lean && block <= 128 && !c.dlog && full && light)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(2 * block), 0,
-                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-            else if (HAS_LEAN && lean && block <= 128 && full && light)  // ... with the delta log of the replica exchange
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(2 * block), 0,
-                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-            else if (HAS_LEAN && lean && block <= 128 && !c.dlog && full)  // (+ one draw-producing wavefront per wavefront of agents)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
-                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-            else if (HAS_LEAN && lean && block <= 128 && !c.dlog)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 1 : 0, HAS_LEAN, false>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
-                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-            else if (HAS_LEAN && lean && block <= 128 && full)  // the same with the delta log of the replica exchange
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, HAS_LEAN>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
-                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-            else if (HAS_LEAN && lean && block <= 128)
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, 128, MK, HAS_LEAN ? 2 : 0, HAS_LEAN, false>), dim3(1), dim3(std::max(512u, 2 * block)), 0,
-                                   e->stream, sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-            else
-                hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, LANE_MAX_AGENTS, MK, 0, false, false>), dim3(1), dim3(block), 0, e->stream,
-                                   sl.sched, c, ev, (long long)steps, FLAG_ACCOUNT);
-        };
-        using Yes = std::true_type;
-        using No = std::false_type;
-        if constexpr (std::is_same<Env, HashEnv>::value) {
-            auto by_mask = [&](auto nv) { if (env->p.masked) go(nv, Yes{}); else go(nv, No{}); };
-            switch (e->ld) {  // a power of two (row_stride)
-                case 4: by_mask(std::integral_constant<int, 1>{}); break;
-                case 8: by_mask(std::integral_constant<int, 2>{}); break;
-                case 16: by_mask(std::integral_constant<int, 4>{}); break;
-                case 32: by_mask(std::integral_constant<int, 8>{}); break;
-                default: by_mask(std::integral_constant<int, 16>{}); break;
-            }
-        } else if constexpr (std::is_same<Env, TttEnv>::value) {
-            go(std::integral_constant<int, 4>{}, Yes{});  // A = 9 -> row stride 16
-        } else {
-            go(std::integral_constant<int, 1>{}, No{});  // GridLake (A = 4) and the bandit (A = 2)
-        }
-        ++sl.launches;
-#ifdef QE_EXPERIMENT
-#undef FLAG_ACCOUNT
-#endif
+        if (int rc = launch_persistent<T, Env>(e, env, sl, c, ev, steps, mode)) return rc;
     } else if (learn) {
-        const int base = FLAG_ACCOUNT;
-        launch_step_any<T, Env>(e, sl, c, ev, base | FLAG_SELECT, false);  // select(0), env.step(0)
-        while ((int)sl.sample_ev.size() < 2 * MAX_SAMPLES) {
-            hipEvent_t evn;
-            HIP_TRY(hipEventCreate(&evn));
-            sl.sample_ev.push_back(evn);
-        }
-        // The steady-state steps all launch the same kernels with the same arguments (the step index
-        // lives in the control block), so a block of GRAPH_STEPS of them is captured once per call
-        // into a HIP graph and replayed: the host no longer pays one launch per kernel.  The first
-        // steps stay eager so that the dominant kernel can be bracketed by events.
-        // (Turnstile path: its launches do not move the step counter themselves; a launch works on step
-        // counter + turn_t_off, `t_base` is the counter's value in stream order.)
-        int64_t done = 0, t_base = 0;
-        auto at_step = [&](int64_t step) { Ctx<T> cc = c; if (turn) cc.turn_t_off = step - t_base; return cc; };
-        auto bump = [&](int64_t by) {
-            hipLaunchKernelGGL(k_turn_bump, dim3(1), dim3(1), 0, e->stream, sl.ctrl, (long long)by);
-            t_base += by;
-        };
-        const int64_t middle = steps - 1;
-        const int64_t eager_head = std::min<int64_t>(middle, 32);
-        for (; done < eager_head; ++done) {
-            const int sample = sl.n_samples < MAX_SAMPLES ? sl.n_samples++ : -1;
-            launch_step_any<T, Env>(e, sl, at_step(done), ev, base | FLAG_LEARN | FLAG_SELECT, true, sample);
-        }
-        if (e->opt_graph && middle - done >= 2 * GRAPH_STEPS) {
-            if (sl.graph_exec) { (void)hipGraphExecDestroy(sl.graph_exec); sl.graph_exec = nullptr; }
-            if (turn) bump(done - t_base);  // the graph's launches count from the counter
-            hipGraph_t graph = nullptr;
-            HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-            const int64_t before = sl.launches;
-            for (int k = 0; k < GRAPH_STEPS; ++k)
-                launch_step_any<T, Env>(e, sl, at_step(t_base + k), ev, base | FLAG_LEARN | FLAG_SELECT, true);
-            if (turn) hipLaunchKernelGGL(k_turn_bump, dim3(1), dim3(1), 0, e->stream, sl.ctrl, (long long)GRAPH_STEPS);
-            const int64_t per_replay = sl.launches - before;
-            sl.launches = before;
-            HIP_TRY(hipStreamEndCapture(e->stream, &graph));
-            const hipError_t ie = hipGraphInstantiate(&sl.graph_exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            HIP_TRY(ie);
-            for (; middle - done >= GRAPH_STEPS; done += GRAPH_STEPS) {
-                HIP_TRY(hipGraphLaunch(sl.graph_exec, e->stream));
-                sl.launches += per_replay;
-                if (turn) t_base += GRAPH_STEPS;
-            }
-        }
-        for (; done < middle; ++done) launch_step_any<T, Env>(e, sl, at_step(done), ev, base | FLAG_LEARN | FLAG_SELECT, true);
-        launch_step_any<T, Env>(e, sl, at_step(middle), ev, base | FLAG_LEARN, true);  // learn(steps-1)
+        if (int rc = launch_stepwise<T, Env>(e, sl, c, ev, steps, turn)) return rc;
+        sl.variant = turn ? QE_VARIANT_TURNSTILE : (wide ? QE_VARIANT_WIDE : QE_VARIANT_STEPWISE);
     } else {
-        // greedy evaluation: no table writes, hence no contention and no ordered path
-        hipLaunchKernelGGL((k_eval<T, Env>), dim3(grid_for(c.N * c.L, FAST_BLOCK)), dim3(FAST_BLOCK), 0,
-                           e->stream, c, ev, (long long)steps);
-        ++sl.launches;
+        if (int rc = launch_eval<T, Env>(e, sl, c, ev, steps)) return rc;
     }
     if (!persistent) {
         HIP_TRY(sl.ep_key_packed.ensure((size_t)e->ep_cap));
@@ -819,10 +318,10 @@ static int wait_host_block(qe_engine* e, RolloutSlot& sl) {
             const hipError_t q = hipStreamQuery(e->stream);
             if (q == hipSuccess) {
                 if (published()) break;
-                return fail(QE_ERR_NO_DEVICE, "the rollout kernel finished without publishing its result block");
+                return qe_fail(QE_ERR_NO_DEVICE, "the rollout kernel finished without publishing its result block");
             }
             if (q != hipErrorNotReady)
-                return fail(QE_ERR_NO_DEVICE, "HIP error %d (%s) while waiting for a rollout", (int)q, hipGetErrorString(q));
+                return qe_fail(QE_ERR_NO_DEVICE, "HIP error %d (%s) while waiting for a rollout", (int)q, hipGetErrorString(q));
         }
         struct timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
@@ -833,7 +332,7 @@ static int wait_host_block(qe_engine* e, RolloutSlot& sl) {
 // Wait for one enqueued rollout and read its results back on the copy stream (the compute stream
 // may already be running the next rollout).
 int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
-    if (!sl.busy) return fail(QE_ERR_INVALID, "no rollout in flight in this slot");
+    if (!sl.busy) return qe_fail(QE_ERR_INVALID, "no rollout in flight in this slot");
     sl.busy = false;
     Ctrl fin{};
     float ms = 0;
@@ -950,6 +449,8 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
             st->dominant_ms = ms; st->dominant_launches = 1; st->dominant_env_steps = sl.steps * sl.N;
         }
         st->device_clock_ms = clock_ms;
+        st->kernel_variant = sl.variant;
+        st->complex_steps = sl.persistent ? (int64_t)fin.pending_total : 0;
     }
 #ifdef QE_TURN_CLOCKS
     if (sl.turn && getenv("QE_PRINT_TURN_CLOCKS")) {
@@ -985,8 +486,8 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
                 seg[16], seg[17], seg[18], seg[19] * 10.0 / sl.steps);
     }
 #endif
-    if (fin.error == ERR_EMPTY_CHOICE) return fail(QE_ERR_INDEX, "Cannot choose from an empty sequence");
-    if (fin.error) return fail(QE_ERR_NO_DEVICE, "ordered path gave up (internal error %u)", fin.error);
+    if (fin.error == ERR_EMPTY_CHOICE) return qe_fail(QE_ERR_INDEX, "Cannot choose from an empty sequence");
+    if (fin.error) return qe_fail(QE_ERR_NO_DEVICE, "ordered path gave up (internal error %u)", fin.error);
     return QE_OK;
 }
 
@@ -999,7 +500,7 @@ int rollout_begin_dispatch(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t s
         case QE_ENV_BANDIT: return rollout_begin_impl<T, BanditEnv>(e, env, sl, steps, mode, learn, trace);
         case QE_ENV_TICTACTOE: return rollout_begin_impl<T, TttEnv>(e, env, sl, steps, mode, learn, trace);
     }
-    return fail(QE_ERR_INVALID, "unknown env kind %d", env->p.kind);
+    return qe_fail(QE_ERR_INVALID, "unknown env kind %d", env->p.kind);
 }
 
 template <class F>
@@ -1010,13 +511,13 @@ int by_kind(int kind, F f) {
         case QE_ENV_BANDIT: return f(BanditEnv{});
         case QE_ENV_TICTACTOE: return f(TttEnv{});
     }
-    return fail(QE_ERR_INVALID, "unknown env kind %d", kind);
+    return qe_fail(QE_ERR_INVALID, "unknown env kind %d", kind);
 }
 
 int check_indices(const int32_t* v, int64_t n, int64_t bound, const char* what) {
     for (int64_t i = 0; i < n; ++i)
         if (v[i] < 0 || v[i] >= bound)
-            return fail(QE_ERR_INDEX, "%s[%lld] = %d is out of range [0, %lld)", what, (long long)i,
+            return qe_fail(QE_ERR_INDEX, "%s[%lld] = %d is out of range [0, %lld)", what, (long long)i,
                         (int)v[i], (long long)bound);
     return QE_OK;
 }
@@ -1031,16 +532,16 @@ const char* qe_last_error(void) { return g_err.c_str(); }
 
 int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed, int32_t dtype,
               int32_t device) {
-    if (!out) return fail(QE_ERR_INVALID, "out is NULL");
+    if (!out) return qe_fail(QE_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (S <= 0 || A <= 0) return fail(QE_ERR_INVALID, "state_size and action_size must be positive");
-    if (dtype != QE_F32 && dtype != QE_F64) return fail(QE_ERR_INVALID, "dtype must be QE_F32 or QE_F64");
+    if (S <= 0 || A <= 0) return qe_fail(QE_ERR_INVALID, "state_size and action_size must be positive");
+    if (dtype != QE_F32 && dtype != QE_F64) return qe_fail(QE_ERR_INVALID, "dtype must be QE_F32 or QE_F64");
     if ((double)S * row_stride(A) >= 4294967296.0)
-        return fail(QE_ERR_UNSUPPORTED, "state_size * padded action_size (%d) must be < 2^32 cells", row_stride(A));
+        return qe_fail(QE_ERR_UNSUPPORTED, "state_size * padded action_size (%d) must be < 2^32 cells", row_stride(A));
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(QE_ERR_NO_DEVICE, "no HIP device visible: the Q-learning engine has no CPU fallback");
-    if (device < 0 || device >= ndev) return fail(QE_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+        return qe_fail(QE_ERR_NO_DEVICE, "no HIP device visible: the Q-learning engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return qe_fail(QE_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
     HIP_TRY(hipSetDevice(device));
     qe_engine* e = new qe_engine();
     {
@@ -1099,7 +600,7 @@ int qe_create(qe_engine** out, int64_t S, int32_t A, double gamma, uint64_t seed
         }
     }
     if (err != hipSuccess) {
-        int code = fail(err == hipErrorOutOfMemory ? QE_ERR_OOM : QE_ERR_NO_DEVICE,
+        int code = qe_fail(err == hipErrorOutOfMemory ? QE_ERR_OOM : QE_ERR_NO_DEVICE,
                         "engine allocation failed: %s", hipGetErrorString(err));
         qe_destroy(e);
         return code;
@@ -1147,7 +648,7 @@ int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_HOST_BLOCK && (value == 0 || value == 1)) { e->opt_host_block = (int)value; return QE_OK; }
     if (option == QE_OPT_LANE_ORDERED_PATH && value >= 0 && value <= 2) { e->opt_lane_ordered = (int)value; return QE_OK; }
     if (option == QE_OPT_TURN_FORWARD && (value == 0 || value == 1)) { e->opt_turn_forward = (int)value; return QE_OK; }
-    return fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
+    return qe_fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 
 int qe_set_stream(qe_engine* e, void* s) {
@@ -1160,8 +661,8 @@ int qe_set_stream(qe_engine* e, void* s) {
 
 // ---- table -----------------------------------------------------------------------------------
 static int table_xfer(qe_engine* e, void* host, int host_dtype, bool up) {
-    if (!host) return fail(QE_ERR_INVALID, "host buffer is NULL");
-    if (host_dtype != QE_F32 && host_dtype != QE_F64) return fail(QE_ERR_INVALID, "bad host dtype");
+    if (!host) return qe_fail(QE_ERR_INVALID, "host buffer is NULL");
+    if (host_dtype != QE_F32 && host_dtype != QE_F64) return qe_fail(QE_ERR_INVALID, "bad host dtype");
     HIP_TRY(hipSetDevice(e->device));
     const size_t hs = host_dtype == QE_F32 ? 4 : 8, ds = e->esize();
     const size_t cells = (size_t)e->S * e->A;
@@ -1194,7 +695,7 @@ static int table_xfer(qe_engine* e, void* host, int host_dtype, bool up) {
 // A range of rows, in the table's own dtype, through the engine's page-locked staging area: the streaming
 // form save() / load() use (a 1e7 x 32 table is 1.28 GB; nothing of that size is allocated on the host).
 static int table_rows(qe_engine* e, void* host, int64_t first, int64_t rows, bool up) {
-    if (!host || first < 0 || rows < 0 || first + rows > e->S) return fail(QE_ERR_INVALID, "row range out of bounds");
+    if (!host || first < 0 || rows < 0 || first + rows > e->S) return qe_fail(QE_ERR_INVALID, "row range out of bounds");
     if (rows == 0) return QE_OK;
     HIP_TRY(hipSetDevice(e->device));
     const size_t ds = e->esize(), row_bytes = (size_t)e->A * ds;
@@ -1235,7 +736,7 @@ int qe_table_download(qe_engine* e, void* host, int32_t host_dtype) {
 int qe_table_cells(qe_engine* e, const int32_t* states, const int32_t* actions, int64_t n, double* vals,
                    int32_t op) {
     if (n == 0) return QE_OK;
-    if (!states || !actions || !vals || op < 0 || op > 2) return fail(QE_ERR_INVALID, "bad argument");
+    if (!states || !actions || !vals || op < 0 || op > 2) return qe_fail(QE_ERR_INVALID, "bad argument");
     if (int rc = check_indices(states, n, e->S, "states")) return rc;
     if (int rc = check_indices(actions, n, e->A, "actions")) return rc;
     HIP_TRY(hipSetDevice(e->device));
@@ -1282,7 +783,7 @@ struct Stager {
 
 int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint8_t* masks, double eps,
                       int32_t deterministic, int32_t* out) {
-    if (n < 0 || (n > 0 && (!states || !out))) return fail(QE_ERR_INVALID, "bad argument");
+    if (n < 0 || (n > 0 && (!states || !out))) return qe_fail(QE_ERR_INVALID, "bad argument");
     if (n == 0) { e->step_ctr += 1; return QE_OK; }
     if (int rc = check_indices(states, n, e->S, "states")) return rc;
     HIP_TRY(hipSetDevice(e->device));
@@ -1377,8 +878,8 @@ int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const 
              const uint8_t* next_masks, int32_t mode) {
     if (n == 0) return QE_OK;
     if (n < 0 || !states || !actions || !rewards || !next_states || !terminated)
-        return fail(QE_ERR_INVALID, "bad argument");
-    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
+        return qe_fail(QE_ERR_INVALID, "bad argument");
+    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return qe_fail(QE_ERR_INVALID, "bad learn mode");
     if (int rc = check_indices(states, n, e->S, "states")) return rc;
     if (int rc = check_indices(actions, n, e->A, "actions")) return rc;
     // the sequential form never reads the next-state row of a terminated transition
@@ -1387,7 +888,7 @@ int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const 
     for (int64_t i = 0; i < n; ++i) {
         if (terminated[i] && mode == QE_LEARN_ITER) nxt[(size_t)i] = states[i];
         else if (nxt[(size_t)i] < 0 || nxt[(size_t)i] >= e->S)
-            return fail(QE_ERR_INDEX, "next_states[%lld] = %d is out of range", (long long)i, (int)nxt[(size_t)i]);
+            return qe_fail(QE_ERR_INDEX, "next_states[%lld] = %d is out of range", (long long)i, (int)nxt[(size_t)i]);
     }
     HIP_TRY(hipSetDevice(e->device));
     if (int rc = learn_buffers(e, n)) return rc;
@@ -1409,26 +910,26 @@ int qe_learn(qe_engine* e, const int32_t* states, const int32_t* actions, const 
 
 // ---- environments ------------------------------------------------------------------------------
 int qe_env_create(qe_env** out, qe_engine* e, int64_t N, const qe_env_params* p) {
-    if (!out || !e || !p || N <= 0) return fail(QE_ERR_INVALID, "bad argument");
+    if (!out || !e || !p || N <= 0) return qe_fail(QE_ERR_INVALID, "bad argument");
     *out = nullptr;
-    if (e->ld > 256) return fail(QE_ERR_UNSUPPORTED, "device environments support action_size <= 256");
+    if (e->ld > 256) return qe_fail(QE_ERR_UNSUPPORTED, "device environments support action_size <= 256");
     switch (p->kind) {
         case QE_ENV_HASH:
-            if (p->p_term_256 < 0 || p->p_term_256 > 256) return fail(QE_ERR_INVALID, "p_term_256 out of range");
+            if (p->p_term_256 < 0 || p->p_term_256 > 256) return qe_fail(QE_ERR_INVALID, "p_term_256 out of range");
             break;
         case QE_ENV_GRID:
             if (p->side < 2 || (int64_t)p->side * p->side != e->S || e->A != 4)
-                return fail(QE_ERR_INVALID, "GridLake needs state_size == side*side and action_size == 4");
+                return qe_fail(QE_ERR_INVALID, "GridLake needs state_size == side*side and action_size == 4");
             break;
         case QE_ENV_BANDIT:
             if (e->S != 1 || e->A != 2 || p->episode_len <= 0)
-                return fail(QE_ERR_INVALID, "bandit needs state_size 1, action_size 2, episode_len > 0");
+                return qe_fail(QE_ERR_INVALID, "bandit needs state_size 1, action_size 2, episode_len > 0");
             break;
         case QE_ENV_TICTACTOE:
             if (e->S != 19683 || e->A != 9)
-                return fail(QE_ERR_INVALID, "TicTacToe needs state_size 19683 (3^9) and action_size 9");
+                return qe_fail(QE_ERR_INVALID, "TicTacToe needs state_size 19683 (3^9) and action_size 9");
             break;
-        default: return fail(QE_ERR_INVALID, "unknown env kind %d", p->kind);
+        default: return qe_fail(QE_ERR_INVALID, "unknown env kind %d", p->kind);
     }
     HIP_TRY(hipSetDevice(e->device));
     qe_env* env = new qe_env();
@@ -1456,7 +957,7 @@ int qe_env_create(qe_env** out, qe_engine* e, int64_t N, const qe_env_params* p)
     if (err == hipSuccess) err = hipMemsetAsync(env->adv_bitmap.p, 0, env->adv_bitmap.cap * 4, e->stream);
     if (err != hipSuccess) {
         qe_env_destroy(env);
-        return fail(QE_ERR_OOM, "env allocation failed: %s", hipGetErrorString(err));
+        return qe_fail(QE_ERR_OOM, "env allocation failed: %s", hipGetErrorString(err));
     }
     *out = env;
     return qe_env_reset(env, 0, 0);
@@ -1537,7 +1038,7 @@ int qe_env_restore(qe_env* env, const int32_t* obs, const uint32_t* aux, const f
 }
 
 int qe_env_aux(qe_env* env, uint32_t* aux) {
-    if (!aux) return fail(QE_ERR_INVALID, "aux is NULL");
+    if (!aux) return qe_fail(QE_ERR_INVALID, "aux is NULL");
     if (env->mirror_aux) { memcpy(aux, env->mirror_aux, (size_t)env->N * 4); return QE_OK; }
     HIP_TRY(hipSetDevice(env->e->device));
     // on the engine's stream (a non-blocking stream: the null stream would not be ordered behind it)
@@ -1549,7 +1050,7 @@ int qe_env_aux(qe_env* env, uint32_t* aux) {
 int qe_env_step(qe_env* env, const int32_t* actions, int32_t* obs, float* rewards, uint8_t* terminated,
                 uint8_t* masks) {
     qe_engine* e = env->e;
-    if (!actions) return fail(QE_ERR_INVALID, "actions is NULL");
+    if (!actions) return qe_fail(QE_ERR_INVALID, "actions is NULL");
     if (int rc = check_indices(actions, env->N, e->A, "actions")) return rc;
     HIP_TRY(hipSetDevice(e->device));
     env_touched(env);
@@ -1571,17 +1072,17 @@ int qe_env_step(qe_env* env, const int32_t* actions, int32_t* obs, float* reward
 // ---- fused rollout / evaluation ------------------------------------------------------------------
 static int begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps, const double* lr, int mode,
                  int learn, int32_t* trace, int slot) {
-    if (!e || !env || env->e != e) return fail(QE_ERR_INVALID, "engine/env mismatch");
-    if (slot < 0 || slot > 1) return fail(QE_ERR_INVALID, "slot must be 0 or 1");
-    if (steps <= 0) return fail(QE_ERR_INVALID, "steps must be > 0");
+    if (!e || !env || env->e != e) return qe_fail(QE_ERR_INVALID, "engine/env mismatch");
+    if (slot < 0 || slot > 1) return qe_fail(QE_ERR_INVALID, "slot must be 0 or 1");
+    if (steps <= 0) return qe_fail(QE_ERR_INVALID, "steps must be > 0");
     const bool use_plan = learn && !eps && !lr;
     if (use_plan && e->plan_cursor + steps > e->plan_count)
-        return fail(QE_ERR_INVALID, "schedule plan exhausted: %lld values left, %lld steps requested",
+        return qe_fail(QE_ERR_INVALID, "schedule plan exhausted: %lld values left, %lld steps requested",
                     (long long)(e->plan_count - e->plan_cursor), (long long)steps);
-    if (learn && !use_plan && (!eps || !lr)) return fail(QE_ERR_INVALID, "eps and lr schedules are required");
-    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
+    if (learn && !use_plan && (!eps || !lr)) return qe_fail(QE_ERR_INVALID, "eps and lr schedules are required");
+    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return qe_fail(QE_ERR_INVALID, "bad learn mode");
     RolloutSlot& sl = e->slots[slot];
-    if (sl.busy) return fail(QE_ERR_INVALID, "slot %d still has a rollout in flight (call qe_rollout_end)", slot);
+    if (sl.busy) return qe_fail(QE_ERR_INVALID, "slot %d still has a rollout in flight (call qe_rollout_end)", slot);
     HIP_TRY(hipSetDevice(e->device));
     if (int rc = slot_prepare(e, sl, steps, learn ? eps : nullptr, learn ? lr : nullptr, use_plan,
                               persistent_path(e, env, learn) && !trace)) return rc;
@@ -1604,8 +1105,8 @@ int qe_rollout_begin(qe_engine* e, qe_env* env, int64_t steps, const double* eps
 }
 
 int qe_schedule_plan(qe_engine* e, const double* eps, const double* lr, int64_t count) {
-    if (!e || count < 0 || (count > 0 && (!eps || !lr))) return fail(QE_ERR_INVALID, "bad argument");
-    if (e->slots[0].busy || e->slots[1].busy) return fail(QE_ERR_INVALID, "a rollout is in flight");
+    if (!e || count < 0 || (count > 0 && (!eps || !lr))) return qe_fail(QE_ERR_INVALID, "bad argument");
+    if (e->slots[0].busy || e->slots[1].busy) return qe_fail(QE_ERR_INVALID, "a rollout is in flight");
     HIP_TRY(hipSetDevice(e->device));
     // (no rollout in flight = every kernel that read the previous plan has completed: qe_rollout_end
     // waited for it.  No host synchronisation here: on ROCm 7.2 a hipStreamSynchronize + H2D copy on
@@ -1635,7 +1136,7 @@ int64_t qe_rollout_chunk_limit(qe_engine* e, qe_env* env, int32_t learn) {
 }
 
 int qe_rollout_end(qe_engine* e, int32_t slot, qe_rollout_stats* stats) {
-    if (!e || slot < 0 || slot > 1) return fail(QE_ERR_INVALID, "bad argument");
+    if (!e || slot < 0 || slot > 1) return qe_fail(QE_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(e->device));
     const double t0 = now_us();
     const int rc = rollout_end(e, e->slots[slot], stats);
@@ -1700,7 +1201,7 @@ int64_t qe_episode_log(qe_engine* e, int64_t cap, int32_t* step, int32_t* agent,
 
 // ---- multi-GPU replica sync --------------------------------------------------------------------
 int qe_delta_log_attach(qe_engine* e, void* dev_buf, int64_t capacity) {
-    if (e->dtype != QE_F32 && dev_buf) return fail(QE_ERR_UNSUPPORTED, "delta log needs a float32 table");
+    if (e->dtype != QE_F32 && dev_buf) return qe_fail(QE_ERR_UNSUPPORTED, "delta log needs a float32 table");
     e->dlog = (DeltaEntry*)dev_buf;
     e->dlog_cap = dev_buf ? capacity : 0;
     e->dlog_count = 0;
@@ -1711,7 +1212,7 @@ int qe_delta_log_reset(qe_engine* e) { e->dlog_count = 0; return QE_OK; }
 
 int qe_delta_apply_dev(qe_engine* e, const void* dev_entries, int64_t count) {
     if (count <= 0) return QE_OK;
-    if (e->dtype != QE_F32) return fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
+    if (e->dtype != QE_F32) return qe_fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_delta_apply<float>, dim3(grid_for(count, 256)), dim3(256), 0, e->stream,
                        (float*)e->q, (const DeltaEntry*)dev_entries, count);
@@ -1721,10 +1222,10 @@ int qe_delta_apply_dev(qe_engine* e, const void* dev_entries, int64_t count) {
 
 int qe_delta_apply_skip_dev(qe_engine* e, const void* dev_entries, int64_t count, int64_t skip_begin,
                             int64_t skip_end) {
-    if (!e || skip_begin < 0 || skip_end < skip_begin || skip_end > count) return fail(QE_ERR_INVALID, "bad argument");
+    if (!e || skip_begin < 0 || skip_end < skip_begin || skip_end > count) return qe_fail(QE_ERR_INVALID, "bad argument");
     const int64_t live = count - (skip_end - skip_begin);
     if (live <= 0) return QE_OK;
-    if (e->dtype != QE_F32) return fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
+    if (e->dtype != QE_F32) return qe_fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_delta_apply_skip<float>, dim3(grid_for(live, 256)), dim3(256), 0, e->stream, (float*)e->q,
                        (const DeltaEntry*)dev_entries, count, skip_begin, skip_end - skip_begin);
@@ -1734,7 +1235,7 @@ int qe_delta_apply_skip_dev(qe_engine* e, const void* dev_entries, int64_t count
 
 int qe_delta_apply_sorted_dev(qe_engine* e, const void* dev_entries, int64_t count) {
     if (count <= 0) return QE_OK;
-    if (e->dtype != QE_F32) return fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
+    if (e->dtype != QE_F32) return qe_fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_delta_apply_sorted<float>, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, (float*)e->q,
                        (const DeltaEntry*)dev_entries, count);
@@ -1744,11 +1245,11 @@ int qe_delta_apply_sorted_dev(qe_engine* e, const void* dev_entries, int64_t cou
 
 // ---- experience replay ring ---------------------------------------------------------------------
 int qe_replay_create(qe_replay** out, int32_t device, int64_t capacity) {
-    if (!out || capacity <= 0) return fail(QE_ERR_INVALID, "capacity must be > 0");
+    if (!out || capacity <= 0) return qe_fail(QE_ERR_INVALID, "capacity must be > 0");
     *out = nullptr;
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(QE_ERR_NO_DEVICE, "no HIP device");
-    if (device < 0 || device >= count) return fail(QE_ERR_INVALID, "device %d out of range", device);
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return qe_fail(QE_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= count) return qe_fail(QE_ERR_INVALID, "device %d out of range", device);
     HIP_TRY(hipSetDevice(device));
     qe_replay* rb = new qe_replay();
     rb->device = device; rb->capacity = capacity;
@@ -1760,7 +1261,7 @@ int qe_replay_create(qe_replay** out, int32_t device, int64_t capacity) {
     if (err == hipSuccess) err = rb->d.ensure(c);
     if (err == hipSuccess) err = rb->bad.ensure(1);
     if (err == hipSuccess) err = hipStreamCreate(&rb->stream);
-    if (err != hipSuccess) { qe_replay_destroy(rb); return fail(QE_ERR_OOM, "replay allocation failed: %s", hipGetErrorString(err)); }
+    if (err != hipSuccess) { qe_replay_destroy(rb); return qe_fail(QE_ERR_OOM, "replay allocation failed: %s", hipGetErrorString(err)); }
     *out = rb;
     return QE_OK;
 }
@@ -1779,7 +1280,7 @@ int qe_replay_destroy(qe_replay* rb) {
 int qe_replay_push(qe_replay* rb, const int64_t* states, const int64_t* actions, const double* rewards,
                    const int64_t* next_states, const uint8_t* done, int64_t n) {
     if (!rb || n < 0 || (n > 0 && (!states || !actions || !rewards || !next_states || !done)))
-        return fail(QE_ERR_INVALID, "bad argument");
+        return qe_fail(QE_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(rb->device));
     const int64_t cap = rb->capacity;
     int64_t first = 0;
@@ -1805,9 +1306,9 @@ int qe_replay_push(qe_replay* rb, const int64_t* states, const int64_t* actions,
 }
 
 int qe_replay_attach(qe_engine* e, qe_replay* rb) {
-    if (!e) return fail(QE_ERR_INVALID, "engine is NULL");
-    if (rb && rb->device != e->device) return fail(QE_ERR_INVALID, "replay buffer and engine live on different devices");
-    if (e->slots[0].busy || e->slots[1].busy) return fail(QE_ERR_INVALID, "a rollout is in flight");
+    if (!e) return qe_fail(QE_ERR_INVALID, "engine is NULL");
+    if (rb && rb->device != e->device) return qe_fail(QE_ERR_INVALID, "replay buffer and engine live on different devices");
+    if (e->slots[0].busy || e->slots[1].busy) return qe_fail(QE_ERR_INVALID, "a rollout is in flight");
     if (e->replay) e->replay->attached = nullptr;
     if (rb) {
         if (rb->attached && rb->attached != e) rb->attached->replay = nullptr;
@@ -1827,7 +1328,7 @@ static int replay_indices(qe_replay* rb, const int64_t* indices, int64_t n) {
     for (int64_t i = 0; i < n; ++i) {
         if (idx[(size_t)i] < 0) idx[(size_t)i] += rb->capacity;
         if (idx[(size_t)i] < 0 || idx[(size_t)i] >= rb->capacity)
-            return fail(QE_ERR_INDEX, "index %lld is out of bounds for axis 0 with size %lld", (long long)indices[i],
+            return qe_fail(QE_ERR_INDEX, "index %lld is out of bounds for axis 0 with size %lld", (long long)indices[i],
                         (long long)rb->capacity);
     }
     HIP_TRY(rb->idx.ensure((size_t)n));
@@ -1839,7 +1340,7 @@ static int replay_indices(qe_replay* rb, const int64_t* indices, int64_t n) {
 int qe_replay_gather(qe_replay* rb, const int64_t* indices, int64_t n, int64_t* states, int64_t* actions,
                      double* rewards, int64_t* next_states, uint8_t* done) {
     if (!rb || n < 0 || (n > 0 && (!indices || !states || !actions || !rewards || !next_states || !done)))
-        return fail(QE_ERR_INVALID, "bad argument");
+        return qe_fail(QE_ERR_INVALID, "bad argument");
     if (n == 0) return QE_OK;
     HIP_TRY(hipSetDevice(rb->device));
     if (int rc = replay_indices(rb, indices, n)) return rc;
@@ -1860,9 +1361,9 @@ int qe_replay_gather(qe_replay* rb, const int64_t* indices, int64_t n, int64_t* 
 }
 
 int qe_replay_learn(qe_replay* rb, qe_engine* e, const int64_t* indices, int64_t n, double lr, int32_t mode) {
-    if (!rb || !e || n < 0 || (n > 0 && !indices)) return fail(QE_ERR_INVALID, "bad argument");
-    if (rb->device != e->device) return fail(QE_ERR_INVALID, "replay buffer and engine live on different devices");
-    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return fail(QE_ERR_INVALID, "bad learn mode");
+    if (!rb || !e || n < 0 || (n > 0 && !indices)) return qe_fail(QE_ERR_INVALID, "bad argument");
+    if (rb->device != e->device) return qe_fail(QE_ERR_INVALID, "replay buffer and engine live on different devices");
+    if (mode != QE_LEARN_ITER && mode != QE_LEARN_VEC) return qe_fail(QE_ERR_INVALID, "bad learn mode");
     if (n == 0) return QE_OK;
     HIP_TRY(hipSetDevice(e->device));
     if (int rc = replay_indices(rb, indices, n)) return rc;
@@ -1875,7 +1376,7 @@ int qe_replay_learn(qe_replay* rb, qe_engine* e, const int64_t* indices, int64_t
     unsigned bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, rb->bad.p, sizeof bad, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (bad) return fail(QE_ERR_INDEX, "%u sampled experiences hold a state / action outside the table", bad);
+    if (bad) return qe_fail(QE_ERR_INDEX, "%u sampled experiences hold a state / action outside the table", bad);
     return learn_launch(e, n, lr, false, mode);
 }
 

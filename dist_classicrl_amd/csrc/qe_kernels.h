@@ -194,7 +194,7 @@ __device__ __forceinline__ void log_episode(const Ctx<T>& c, long long t, int64_
 
 // The 64 segments of the step-wise episode log, packed back to back (one workgroup per segment), so
 // that the host fetches the log of a rollout with two copies.
-__global__ __launch_bounds__(256) void k_log_gather(const Ctrl* ctrl, const unsigned long long* key, const float* ret,
+static __global__ __launch_bounds__(256) void k_log_gather(const Ctrl* ctrl, const unsigned long long* key, const float* ret,
                                                     long long ep_cap, unsigned long long* key_out, float* ret_out) {
     const long long seg_cap = ep_cap >> 6;
     const int seg = (int)blockIdx.x;
@@ -1413,7 +1413,7 @@ __global__ void k_delta_apply_sorted(T* q, const DeltaEntry* e, int64_t count) {
 }
 
 // ---- experience replay ring (experience_replay.py): gather of sampled entries ---------------------
-__global__ void k_replay_gather(const int64_t* rs, const int64_t* ra, const double* rr, const int64_t* rn,
+static __global__ void k_replay_gather(const int64_t* rs, const int64_t* ra, const double* rr, const int64_t* rn,
                                 const uint8_t* rd, const int64_t* idx, int64_t n, int64_t* s, int64_t* a,
                                 double* r, int64_t* s2, uint8_t* d) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1423,7 +1423,7 @@ __global__ void k_replay_gather(const int64_t* rs, const int64_t* ra, const doub
 }
 // the same, straight into the batch buffers of qe_learn (narrowed to its types; `bad` counts entries
 // whose state / action / next state does not fit the table)
-__global__ void k_replay_to_batch(const int64_t* rs, const int64_t* ra, const double* rr, const int64_t* rn,
+static __global__ void k_replay_to_batch(const int64_t* rs, const int64_t* ra, const double* rr, const int64_t* rn,
                                   const uint8_t* rd, const int64_t* idx, int64_t n, int64_t S, int32_t A, int iter_mode,
                                   int32_t* s, int32_t* a, float* r, int32_t* s2, uint8_t* d, unsigned* bad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

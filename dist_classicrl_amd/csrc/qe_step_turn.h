@@ -398,6 +398,6 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
 // Step counter of the turnstile path: the launches of a captured graph carry their offsets 0 .. G-1 as launch
 // arguments and the graph ends with this one-thread kernel (+G); eager launches carry the offset from the counter's
 // current value.
-__global__ void k_turn_bump(Ctrl* ctrl, long long by) { ctrl->t_local += by; }
+static __global__ void k_turn_bump(Ctrl* ctrl, long long by) { ctrl->t_local += by; }
 
 }  // namespace qe

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QE_ABI_VERSION 1
+#define QE_ABI_VERSION 2
 
 typedef struct qe_engine qe_engine;
 typedef struct qe_env qe_env;
@@ -83,6 +83,13 @@ typedef struct qe_rollout_stats {
     double device_clock_ms;  /* persistent path: in-kernel constant-rate clock, launch start -> results published (0 otherwise) */
     double host_begin_us;    /* host time spent inside qe_rollout_begin (enqueue) ... */
     double host_end_us;      /* ... and inside qe_rollout_end (wait + result hand-over) */
+    int64_t kernel_variant;  /* which kernel build ran.  bits 0-3 path: 1 step-wise, 2 persistent, 3 wide, 4 turnstile,
+                                5 evaluation; persistent path: bits 4-5 LEAN (0 generic build, 1 plain training rollout,
+                                2 the same with the delta log), bit 6 draw-producing helper wavefronts, bit 7 every lane an
+                                agent, bit 8 built without the general ordered path ("light"), bit 9 the 512-agent build,
+                                bits 12-19 16-byte loads per row, bit 20 masked environment (tests assert on these) */
+    int64_t complex_steps;   /* persistent path: vector steps in which some contested row had more than two touchers (the
+                                steps the "light" build works off one deferred agent per round) */
 } qe_rollout_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------

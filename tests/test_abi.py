@@ -25,14 +25,14 @@ def test_header_symbols_are_exported_and_bound():
     for name in names:
         assert hasattr(lib, name), f"{name} is declared in the header but not exported"
     assert sorted(_lib.PROTOTYPES) == names
-    assert _lib.load().qe_abi_version() == 1
+    assert _lib.load().qe_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_layouts_match_the_header():
     from dist_classicrl_amd import _lib
 
     assert ctypes.sizeof(_lib.EnvParams) == 32
-    assert ctypes.sizeof(_lib.RolloutStats) == 88
+    assert ctypes.sizeof(_lib.RolloutStats) == 104
 
 
 def test_no_cpu_fallback():

@@ -1,0 +1,249 @@
+"""GPU: the kernel builds a USER gets -- and ``bench.py`` times -- against the oracle.
+
+Every closed-loop comparison of ``test_gpu_parity.py`` collects an action trace, and a traced rollout of up to
+512 agents runs the generic build of the persistent kernel (``k_rollout_lane<..., 512, MK, 0, false, false>``).
+Plain training rollouts of up to 128 agents take other instantiations of that kernel (``LEAN`` 1 / 2, ``HELP``
+draw-producing wavefronts, ``FULL`` wavefronts, ``SEQ`` = the "light" build without the general ordered path:
+``csrc/qe_inst_lane.hip``) -- different functions with different register allocation.  Here those builds are
+run exactly as a user runs them (no trace; ``qe_rollout_fused`` calls of 20 / 64 / 2000 steps and the pipelined
+``qe_rollout_begin`` / ``qe_rollout_end`` path) and everything a rollout leaves behind -- the whole Q-table, the
+episode returns in order, the final observations, the running returns -- must equal the oracle bit for bit
+(reference: ``base_runtime.py:184-222`` driven by ``single_thread_runtime.py:63-75``).  Each test asserts through
+``qe_rollout_stats.kernel_variant`` that the build it means to cover is the one that ran.
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import run_oracle_trace
+
+pytestmark = pytest.mark.gpu
+
+
+def _product():
+    from dist_classicrl_amd import _lib, environments, schedules
+    from dist_classicrl_amd.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
+    from dist_classicrl_amd.algorithms.runtime.gpu_rollout_runtime import GpuRolloutQLearning
+
+    return _lib, OptimalQLearningBase, GpuRolloutQLearning, environments, schedules
+
+
+def _bench_runtime(algo, sch, Runtime):
+    return Runtime(algo, sch.ExponentialSchedule(0.1, 1e-5, 0.995), sch.ExponentialSchedule(1.0, 0.01, 0.995))
+
+
+def _c_oracle_run(n, S, A, steps, *, masked=False, delta_log=False):
+    from oracle import c_oracle
+
+    ref = c_oracle.CHashRollout(n, S, A, masked=masked, dtype=np.float32)
+    eps, _ = c_oracle.exp_schedule(1.0, 0.01, 0.995, n, steps)
+    lr, _ = c_oracle.exp_schedule(0.1, 1e-5, 0.995, n, steps)
+    out = ref.run(eps, lr, trace=True, delta_log=delta_log)
+    return ref, out
+
+
+def _run_in_calls(rt, env, calls):
+    """run_steps call by call, handing the state dict back (single_thread_runtime.py:58-61)."""
+    sd, history, variants, complex_steps = None, [], set(), 0
+    for k in calls:
+        try:
+            _avg, h, env, sd = rt.run_steps(k, env, sd)
+        except ZeroDivisionError:  # no episode ended in this call (reference quirk); the state moved on all the same
+            h, sd = [], env.state_dict()
+        history += h
+        variants.update(rt.last_stats["kernel_variants"])
+        complex_steps += rt.last_stats["complex_steps"]
+    return history, sd, variants, complex_steps
+
+
+def _split(total, k):
+    return [k] * (total // k) + ([total % k] if total % k else [])
+
+
+def _assert_lane_build(_lib, variants, *, lean, light, full=True, help_=True, nv=None, masked=None):
+    assert variants, "no launch was recorded"
+    for v in variants:
+        d = _lib.decode_variant(v)
+        assert d["path"] == "persistent", d
+        assert d["lean"] == lean and d["help"] == help_ and d["full"] == full and d["light"] == light, d
+        assert not d["cap512"], d
+        if nv is not None:
+            assert d["nv"] == nv, d
+        if masked is not None:
+            assert d["masked"] == masked, d
+
+
+HEADLINE = (128, 1_000_000, 16, 3000)
+C2 = (128, 10_000, 8, 1500)
+
+
+@pytest.mark.parametrize("calls", ["20", "64", "2000", "pipelined"])
+@pytest.mark.parametrize("ordered_path", [1, 2])  # QE_OPT_LANE_ORDERED_PATH: 1 = light (SEQ) build, 2 = full build
+@pytest.mark.parametrize("shape", ["headline", "c2"])
+def test_plain_training_rollout_builds_match_c_oracle(shape, ordered_path, calls):
+    """BASELINE's 128-agent shapes, benchmark schedules, NO action trace: LEAN = 1, HELP, FULL, SEQ = light."""
+    _lib, Algo, Runtime, envs, sch = _product()
+    n, S, A, steps = HEADLINE if shape == "headline" else C2
+    algo = Algo(S, A, 0.99, seed=0)
+    algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, ordered_path)
+    rt = _bench_runtime(algo, sch, Runtime)
+    env = envs.HashTabularEnv(n, S, A, seed=1)
+    plan = [steps] if calls == "pipelined" else _split(steps, int(calls))  # 3000 > one launch's log: begin/end chunks
+    history, sd, variants, complex_steps = _run_in_calls(rt, env, plan)
+    _assert_lane_build(_lib, variants, lean=1, light=ordered_path == 1, nv=A // 4, masked=False)
+    if shape == "c2":
+        assert complex_steps > 0  # rows with more than two touchers: the light build's one-agent-per-round fallback ran
+    ref, want = _c_oracle_run(n, S, A, steps)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    assert np.array_equal(sd["states"], ref.obs)
+    assert np.array_equal(sd["rewards"], ref.acc)
+    assert algo.step_counter == steps
+
+
+@pytest.mark.parametrize("ordered_path", [1, 2])
+@pytest.mark.parametrize(("n", "S", "A", "steps"), [
+    (128, 60, 16, 200),    # two wavefronts of agents on 60 states: nearly every step complex
+    (64, 25, 8, 150),      # one wavefront, NV = 2
+    (128, 4000, 16, 400),  # mostly quiet / two-toucher steps, a few complex ones
+    (64, 3000, 16, 300),
+])
+def test_contested_shapes_through_the_lean_builds(n, S, A, steps, ordered_path):
+    """Forced light / full builds where steps with more than two touchers per row are the rule (the SEQ fallback of
+    the light build, slow_body of the full one) -- no trace."""
+    _lib, Algo, Runtime, envs, sch = _product()
+    algo = Algo(S, A, 0.99, seed=0)
+    algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, ordered_path)
+    rt = _bench_runtime(algo, sch, Runtime)
+    history, sd, variants, complex_steps = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), _split(steps, 50))
+    _assert_lane_build(_lib, variants, lean=1, light=ordered_path == 1, nv=A // 4)
+    if S <= 60:
+        assert complex_steps > steps // 2
+    ref, want = _c_oracle_run(n, S, A, steps)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    assert np.array_equal(sd["states"], ref.obs)
+    assert np.array_equal(sd["rewards"], ref.acc)
+
+
+@pytest.mark.parametrize(("n", "S", "A"), [(100, 5000, 16), (37, 900, 8), (1, 50, 16)])
+def test_partly_filled_wavefronts_take_the_lean_build_without_full(n, S, A):
+    """Agent counts that are not a multiple of 64: LEAN = 1, HELP, not FULL, never light."""
+    _lib, Algo, Runtime, envs, sch = _product()
+    algo = Algo(S, A, 0.99, seed=0)
+    rt = _bench_runtime(algo, sch, Runtime)
+    steps = 300
+    history, sd, variants, _ = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), _split(steps, 64))
+    _assert_lane_build(_lib, variants, lean=1, light=False, full=False, nv=A // 4)
+    ref, want = _c_oracle_run(n, S, A, steps)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    assert np.array_equal(sd["states"], ref.obs)
+    assert np.array_equal(sd["rewards"], ref.acc)
+
+
+@pytest.mark.parametrize("ordered_path", [1, 2])
+@pytest.mark.parametrize("n", [128, 64, 90])
+def test_tictactoe_lean_builds_match_the_oracle(n, ordered_path):
+    """The reference's own benchmark environment (tiktaktoe_mod.py:67-237) on its LEAN build (masked, NV = 4),
+    against the NumPy oracle -- no trace, pipelined begin/end path (masked environments do not take the fused call)."""
+    _lib, Algo, Runtime, envs, sch = _product()
+    steps = 60
+    algo = Algo(19683, 9, 0.99, seed=0)
+    algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, ordered_path)
+    rt = _bench_runtime(algo, sch, Runtime)
+    env = envs.TicTacToeEnv(n, seed=1)
+    history, sd, variants, _ = _run_in_calls(rt, env, [25, 35])
+    full = n % 64 == 0
+    _assert_lane_build(_lib, variants, lean=1, light=ordered_path == 1 and full, full=full, nv=4, masked=True)
+    want = run_oracle_trace(("ttt", n), steps, "f4", "bench", "iter")
+    assert np.array_equal(np.asarray(algo.q_table), want["q"])
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    assert np.array_equal(sd["states"]["observation"], want["final_obs"])
+    assert np.array_equal(sd["rewards"], want["agent_rewards"])
+
+
+@pytest.mark.parametrize("ordered_path", [1, 2])
+@pytest.mark.parametrize(("n", "S", "A", "steps", "call"), [
+    (128, 1_000_000, 16, 600, 20), (128, 10_000, 8, 400, 50), (96, 4000, 8, 300, 64), (128, 60, 16, 120, 40),
+])
+def test_delta_log_builds_record_every_action_and_increment(n, S, A, steps, call, ordered_path):
+    """LEAN = 2 (the builds a replica runs: same loop + one {cell, delta} record per agent-step).  The log is the
+    action trace these builds can give: cell = s * ld + a of EVERY agent-step and the float32 increment it applied must
+    equal the C oracle's, so actions are checked step by step on a LEAN build, not only through the final table."""
+    torch = pytest.importorskip("torch")
+    _lib, Algo, Runtime, envs, sch = _product()
+    lib = _lib.load()
+    algo = Algo(S, A, 0.99, seed=0)
+    algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, ordered_path)
+    log = torch.zeros((steps * n, 2), dtype=torch.int32, device="cuda:0")
+    _lib.check(lib.qe_delta_log_attach(algo.handle, C.c_void_p(log.data_ptr()), steps * n))
+    torch.cuda.synchronize()
+    rt = _bench_runtime(algo, sch, Runtime)
+    history, sd, variants, _ = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), _split(steps, call))
+    full = n % 64 == 0
+    _assert_lane_build(_lib, variants, lean=2, light=ordered_path == 1 and full, full=full, nv=A // 4)
+    _lib.check(lib.qe_synchronize(algo.handle))
+    assert lib.qe_delta_log_count(algo.handle) == steps * n
+    got = log.cpu().numpy()
+    _lib.check(lib.qe_delta_log_attach(algo.handle, None, 0))
+    ref, want = _c_oracle_run(n, S, A, steps, delta_log=True)
+    ld = int(lib.qe_table_row_stride(algo.handle))
+    cells = got[:, 0].view(np.uint32)
+    assert np.array_equal(cells % ld, want["actions"].reshape(-1).astype(np.uint32))  # every action of every step
+    assert np.array_equal(cells // ld * A + cells % ld, want["cells"])
+    assert np.array_equal(got[:, 1].view(np.float32), want["deltas"])
+    assert np.array_equal(np.asarray(algo.q_table), ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    assert np.array_equal(sd["states"], ref.obs)
+
+
+def test_automatic_build_choice_follows_the_contention():
+    """QE_OPT_LANE_ORDERED_PATH = 0: light build while steps with more than two touchers per row are rare, the full
+    build once a launch met many, light again after a launch without any -- results equal the oracle throughout."""
+    _lib, Algo, Runtime, envs, sch = _product()
+    n, S, A = 128, 1_000_000, 16
+    algo = Algo(S, A, 0.99, seed=0)
+    rt = _bench_runtime(algo, sch, Runtime)
+    history, sd, variants, _ = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), [100] * 8)
+    assert any(_lib.decode_variant(v)["light"] for v in variants)
+    ref, want = _c_oracle_run(n, S, A, 800)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    # dense shape: the first launch counts complex steps, the following ones take the full build
+    n, S, A = 128, 200, 16
+    algo = Algo(S, A, 0.99, seed=0)
+    rt = _bench_runtime(algo, sch, Runtime)
+    history, sd, variants, complex_steps = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), [100] * 4)
+    assert complex_steps > 0 and any(not _lib.decode_variant(v)["light"] for v in variants)
+    ref, want = _c_oracle_run(n, S, A, 400)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    assert np.array_equal(sd["states"], ref.obs)
+
+
+@pytest.mark.parametrize(("path", "n", "S", "A", "masked", "steps", "want_path"), [
+    ("auto", 4096, 1_000_000, 16, False, 120, "turnstile"),
+    ("auto", 1024, 1_000_000, 64, True, 80, "turnstile"),
+    ("stepwise", 700, 30_000, 16, False, 60, "stepwise"),
+    ("wide", 4096, 200_000, 16, False, 40, "wide"),
+    ("auto", 300, 5000, 16, False, 100, "persistent"),  # 129..512 agents: the generic persistent build, untraced
+])
+def test_untraced_rollouts_of_the_other_paths_match_c_oracle(path, n, S, A, masked, steps, want_path):
+    """The step-wise / wide / turnstile kernels have one build each (a trace is a run-time pointer there), but the
+    untraced call path differs on the host side (pipelined begin / end, packed episode log): same comparison."""
+    _lib, Algo, Runtime, envs, sch = _product()
+    algo = Algo(S, A, 0.99, seed=0)
+    algo.set_rollout_path(path)
+    rt = _bench_runtime(algo, sch, Runtime)
+    env = envs.HashTabularEnv(n, S, A, seed=1, masked=masked)
+    history, sd, variants, _ = _run_in_calls(rt, env, _split(steps, 50))
+    assert {_lib.decode_variant(v)["path"] for v in variants} == {want_path}
+    ref, want = _c_oracle_run(n, S, A, steps, masked=masked)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    obs = sd["states"]["observation"] if masked else sd["states"]
+    assert np.array_equal(obs, ref.obs)
+    assert np.array_equal(sd["rewards"], ref.acc)

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Turnstile path: parity cases, then bench lines with / without value forwarding (results are identical; timing switch),
 # then -- if a -DQE_TURN_CLOCKS build of the engine lies at tools/libqe_turn_clocks.so -- where a launch spends its time.
-# That build (in the container, before gpurun):  bash dist_classicrl_amd/csrc/build.sh -DQE_TURN_CLOCKS -o ../../tools/libqe_turn_clocks.so
+# That build (in the container, before gpurun):  bash dist_classicrl_amd/csrc/build.sh EXTRA=-DQE_TURN_CLOCKS OBJ=build_clocks LIB=../../tools/libqe_turn_clocks.so
 # (the later -o wins; *.so files are git-ignored but travel to the GPU box).
 set -e
 mkdir -p gpurun_out
