@@ -219,7 +219,10 @@ class OptimalQLearningBase:
             _lib.check(self._lib.qe_table_upload_rows(self._h, block.ctypes.data, first, block.shape[0]))
 
     # ------------------------------------------------------------------ selection (:263-726)
-    def _select(self, states, exploration_rate, deterministic, action_masks, numpy_variant=False):
+    def _select(self, states, exploration_rate, deterministic, action_masks, numpy_variant=False, numpy_max=None):
+        # numpy_variant: the NumPy variants' treatment of an all-zero mask; numpy_max: np.max as the row maximum
+        # (NaN-propagating; every NumPy variant) instead of the list variants' scan (steps over NaN)
+        numpy_max = numpy_variant if numpy_max is None else numpy_max
         states = _lib.as_i32(states).ravel()
         n = states.size
         masks = None
@@ -231,7 +234,7 @@ class OptimalQLearningBase:
         out = np.empty(n, dtype=np.int32)
         _lib.check(self._lib.qe_choose_actions(
             self._h, _lib.ptr(states, C.c_int32), n, _lib.ptr(masks, C.c_uint8),
-            float(exploration_rate), (1 if deterministic else 0) | (2 if numpy_variant else 0),
+            float(exploration_rate), (1 if deterministic else 0) | (2 if numpy_variant else 0) | (4 if numpy_max else 0),
             _lib.ptr(out, C.c_int32)))
         return out
 
@@ -259,7 +262,7 @@ class OptimalQLearningBase:
         return self._raise_on_empty(self._select(states, exploration_rate, deterministic, action_masks, True))
 
     def choose_actions_vec(self, states, exploration_rate, *, deterministic=False):
-        return self._raise_on_empty(self._select(states, exploration_rate, deterministic, None))
+        return self._raise_on_empty(self._select(states, exploration_rate, deterministic, None, numpy_max=True))
 
     def choose_masked_actions_vec(self, states, action_masks, exploration_rate, *, deterministic=False):
         return self._raise_on_empty(self._select(states, exploration_rate, deterministic, action_masks, True))
@@ -281,7 +284,7 @@ class OptimalQLearningBase:
         return int(self._select([state], exploration_rate, deterministic, np.asarray(action_mask)[None, :])[0])
 
     def choose_action_vec(self, state, exploration_rate, *, deterministic=False):
-        return int(self._raise_on_empty(self._select([state], exploration_rate, deterministic, None))[0])
+        return int(self._raise_on_empty(self._select([state], exploration_rate, deterministic, None, numpy_max=True))[0])
 
     def choose_masked_action_vec(self, state, action_mask, exploration_rate, *, deterministic=False):
         mask = np.asarray(list(action_mask))

@@ -203,14 +203,42 @@ __device__ __forceinline__ double group_pick(double mine, bool chosen) {
     return __hiloint2double((int)hi, (int)lo);
 }
 
-// max over the valid columns of this lane's 4 elements, reduced over the group (-inf if none).
+// max over the valid columns of this lane's 4 elements, reduced over the group (-inf if none).  A NaN column is
+// SKIPPED: the scan of the reference's list variants (`if v > max_val`, q_learning_optimal.py:290-296, :337-344).
 template <int LC = 0, typename T>
-__device__ __forceinline__ T row_max_valid(const Row4<T>& row, uint32_t valid4, int L) {
+__device__ __forceinline__ T row_max_skipnan(const Row4<T>& row, uint32_t valid4, int L) {
     T m = neg_inf<T>();
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if ((valid4 >> j) & 1u) m = row.v[j] > m ? row.v[j] : m;
     return group_max<LC>(m, L);
+}
+
+template <typename T>
+__device__ __forceinline__ T quiet_nan() {
+    return (T)__builtin_nanf("");
+}
+
+// whether some valid column of the group's row holds a NaN (all lanes of a lane group call it together; groups
+// are aligned to their width): one ballot, each group looks at its own bits.
+template <int LC = 0, typename T>
+__device__ __forceinline__ bool row_has_nan(const Row4<T>& row, uint32_t valid4, int L) {
+    if (LC) L = LC;
+    bool mine = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mine |= ((valid4 >> j) & 1u) && row.v[j] != row.v[j];
+    const unsigned long long b = __ballot(mine);
+    if (L >= 64) return b != 0ull;
+    const int base = (int)__lane_id() & ~(L - 1);
+    return ((b >> base) & ((1ull << L) - 1ull)) != 0ull;
+}
+
+// np.max over the valid columns (q_learning_optimal.py:548, :757-761, :884-888; the TD target of every learn variant
+// and the greedy pick of the NumPy selection variants): NaN as soon as one valid column holds a NaN.
+template <int LC = 0, typename T>
+__device__ __forceinline__ T row_max_valid(const Row4<T>& row, uint32_t valid4, int L) {
+    const T m = row_max_skipnan<LC>(row, valid4, L);
+    return row_has_nan<LC>(row, valid4, L) ? quiet_nan<T>() : m;
 }
 
 // columns < A of this lane, as a 4-bit field
@@ -223,11 +251,15 @@ __device__ __forceinline__ uint32_t in_range4(int sub, int A) {
 // q_learning_optimal.py:263-642): explore -> k-th valid action, k = mulhi(x1, n_valid);
 // greedy -> k-th action tied at the valid maximum, k = mulhi(x2, n_ties).  Returns -1 when no
 // action is selectable.  *picked_q receives Q[s, action] as held in `row`.
+// `nan_max`: the row maximum is NumPy's (NaN when a valid column holds one: nothing ties with it, no greedy pick is
+// possible and the reference's random.choice raises, :430, :470, :563, :628) -- the NumPy variants; false = the
+// list variants' scan, which steps over NaN columns (:290-296, :337-344).
 template <int LC = 0, typename T>
 __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4, int sub, int L,
-                                             bool explore, uint32_t x1, uint32_t x2, T* picked_q) {
+                                             bool explore, uint32_t x1, uint32_t x2, T* picked_q, bool nan_max) {
     if (LC) L = LC;
-    const T m = row_max_valid<LC>(row, valid4, L);
+    T m = row_max_skipnan<LC>(row, valid4, L);
+    if (nan_max && row_has_nan<LC>(row, valid4, L)) m = quiet_nan<T>();
     uint32_t f = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

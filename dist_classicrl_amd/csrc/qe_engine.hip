@@ -200,6 +200,14 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                        int32_t* trace_host) {
     Ctx<T> c = env_ctx<T>(e, env);
     c.mode = mode;
+    {   // Which family of selection variants the reference's dispatcher runs at this shape (q_learning_optimal.py:644-726,
+        // thresholds :14-20): the NumPy ones take np.max of the row (NaN-propagating), the list ones scan past a NaN.
+        const bool masked = env->p.masked != 0 || env->p.kind == QE_ENV_TICTACTOE;
+        const bool list_variant = !learn ? e->A <= 10                   // deterministic (evaluate_*): :673
+                                         : (masked ? e->A <= 10         // :713
+                                                   : env->N < 100);     // :700
+        c.nan_select = list_variant ? 0 : 1;
+    }
     c.ctrl = sl.ctrl;
     c.thr = (const QE_AS4 unsigned long long*)sl.thr.p; c.lr = (const QE_AS4 double*)sl.lr.p;
     if (sl.plan_offset >= 0) {

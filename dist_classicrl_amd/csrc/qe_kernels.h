@@ -142,6 +142,9 @@ struct Ctx {
     unsigned long long step0;
     double gamma;
     int32_t mode;
+    // selection: the row maximum is NumPy's (NaN-propagating) -- set when the reference's dispatcher would run a NumPy
+    // variant at this shape (q_learning_optimal.py:644-726), clear for its list variants, whose scan steps over NaN
+    int32_t nan_select;
     // logs
     unsigned long long* ep_key;
     float* ep_ret;
@@ -257,7 +260,7 @@ __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx
                                                    int flags, const U4& x, Pending<T>& p) {
     const bool explore = !(flags & FLAG_DETERMINISTIC) && (unsigned long long)x.x < c.thr[t1];
     T picked;
-    int act = select_action<LC>(row, valid, sub, c.L, explore, x.y, x.z, &picked);
+    int act = select_action<LC>(row, valid, sub, c.L, explore, x.y, x.z, &picked, c.nan_select != 0);
     if (act < 0) {
         // No selectable action: every action masked, or the row maximum is NaN (diverged training), where
         // the reference's random.choice raises IndexError (q_learning_optimal.py:470,563).  Reported
@@ -1185,7 +1188,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_eval(Ctx<T> c, EnvCtx ev, long l
         const U4 x = philox4x32_10(c.agent_offset + (uint32_t)i, (uint32_t)step, (uint32_t)(step >> 32),
                                    STREAM_POLICY, c.seed_lo, c.seed_hi);
         T picked;
-        const int act = select_action(row, Env::valid4(ev, i, n, sub), sub, c.L, false, x.y, x.z, &picked);
+        const int act = select_action(row, Env::valid4(ev, i, n, sub), sub, c.L, false, x.y, x.z, &picked, c.nan_select != 0);
         const Transition tr = Env::step(ev, i, n, aux, act, step);  // computed redundantly by every lane
         acc += tr.reward;
         if (tr.terminated) {
@@ -1214,7 +1217,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_select(Ctx<T> c, EnvCtx ev, cons
                                (uint32_t)(c.step0 >> 32), STREAM_POLICY, c.seed_lo, c.seed_hi);
     const bool explore = !(deterministic & 1) && (unsigned long long)x.x < thr;
     T picked;
-    int act = select_action(row, valid, sub, c.L, explore, x.y, x.z, &picked);
+    int act = select_action(row, valid, sub, c.L, explore, x.y, x.z, &picked, (deterministic & 4) != 0);
     // NumPy variants of the reference, agent without a valid action: where(mask, Q, -inf) is all -inf, so
     // every action ties at the maximum and the greedy pick is uniform over ALL actions (:497-503, :618-628)
     if (act < 0 && (deterministic & 2) && ev.masked && !explore) act = (int)mulhi32(x.z, (uint32_t)c.A);
@@ -1237,9 +1240,11 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_select_large(Ctx<T> c, EnvCtx ev
                                (uint32_t)(c.step0 >> 32), STREAM_POLICY, c.seed_lo, c.seed_hi);
     const bool explore = !(deterministic & 1) && (unsigned long long)x.x < thr;
     T m = neg_inf<T>();
+    bool nan = false;
     for (int col = lane; col < c.A; col += 64)
-        if (ok(col)) m = row[col] > m ? row[col] : m;
+        if (ok(col)) { m = row[col] > m ? row[col] : m; nan |= row[col] != row[col]; }
     m = group_max(m, 64);
+    if ((deterministic & 4) && __any(nan)) m = quiet_nan<T>();  // NumPy variants: np.max returns the NaN (see select_action)
     int total = 0;
     for (int col = lane; col < c.A; col += 64) total += ok(col) && (explore || row[col] == m);
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
@@ -1276,9 +1281,11 @@ __global__ __launch_bounds__(64) void k_learn_large(Ctx<T> c, EnvCtx ev, double 
             const T* row = c.q + (int64_t)c.n[i] * c.ld;
             const uint32_t* mw = mbase ? mbase + i * ev.n_words : nullptr;
             T m = neg_inf<T>();
+            bool nan = false;
             for (int col = lane; col < c.A; col += 64)
-                if (!mw || ((mw[col >> 5] >> (col & 31)) & 1u)) m = row[col] > m ? row[col] : m;
+                if (!mw || ((mw[col >> 5] >> (col & 31)) & 1u)) { m = row[col] > m ? row[col] : m; nan |= row[col] != row[col]; }
             m = group_max(m, 64);
+            if (__any(nan)) m = quiet_nan<T>();  // np.max (q_learning_optimal.py:884-888)
             if (lane == 0) {
                 const T q0 = c.q[(int64_t)c.s[i] * c.ld + c.a[i]];
                 if constexpr (sizeof(T) == 4) inc[i] = Td<float>::vec_inc(q0, c.r[i], m, c.term[i] != 0, h);
@@ -1300,12 +1307,15 @@ __global__ __launch_bounds__(64) void k_learn_large(Ctx<T> c, EnvCtx ev, double 
             const T* row = c.q + (int64_t)c.n[i] * c.ld;
             const uint32_t* mw = mbase ? mbase + i * ev.n_words : nullptr;
             m = neg_inf<T>();
+            bool nan = false;
             for (int col = lane; col < c.A; col += 64)
                 if (!mw || ((mw[col >> 5] >> (col & 31)) & 1u)) {
                     const T v = load_live(row + col);
                     m = v > m ? v : m;
+                    nan |= v != v;
                 }
             m = group_max(m, 64);
+            if (__any(nan)) m = quiet_nan<T>();  // np.max (q_learning_optimal.py:757-761)
         }
         if (lane == 0) {
             T* cell = c.q + (int64_t)c.s[i] * c.ld + c.a[i];

@@ -82,13 +82,44 @@ __device__ __forceinline__ RowV<T, NV> masked_row(const RowV<T, NV>& row, M vali
 }
 
 // maximum over a (masked) row; -inf if no column is valid.  maxNum ignores a NaN operand, exactly like
-// the `v > m ? v : m` scans of qe_device.h.
+// row_max_skipnan (qe_device.h) and the scan of the reference's list variants.
 template <typename T, int NV>
 __device__ __forceinline__ T row_max_lane(const RowV<T, NV>& rowm) {
     T m = neg_inf<T>();
 #pragma unroll
     for (int j = 0; j < 4 * NV; ++j) m = lane_fmax(m, rowm.v[j]);
     return m;
+}
+
+// Whether a (masked) row holds a NaN: np.max returns it (q_learning_optimal.py:548, :757-761), the maximum above
+// does not.  Sum of squares: every term is >= 0 or NaN, so no inf - inf can arise and the sum is NaN exactly when
+// some column is (x * x and the adds may overflow to +inf, never to NaN).  Two columns per instruction
+// (v_pk_mul_f32 / v_pk_add_f32 on float2) on a float32 row.  (Contraction is off: mul and add stay separate, which
+// changes nothing here -- only NaN-ness is read.)
+template <int NV>
+__device__ __forceinline__ bool row_nan_lane(const RowV<float, NV>& rowm) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 4 * NV; j += 2) {
+        const f2 x = {rowm.v[j], rowm.v[j + 1]};
+        acc += x * x;
+    }
+    const float s = acc.x + acc.y;
+    return s != s;
+}
+template <int NV>
+__device__ __forceinline__ bool row_nan_lane(const RowV<double, NV>& rowm) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4 * NV; ++j) acc += rowm.v[j] * rowm.v[j];
+    return acc != acc;
+}
+// np.max of a (masked) row
+template <typename T, int NV>
+__device__ __forceinline__ T row_max_np_lane(const RowV<T, NV>& rowm) {
+    const T m = row_max_lane(rowm);
+    return row_nan_lane<NV>(rowm) ? quiet_nan<T>() : m;
 }
 
 // value of column `idx` (0 <= idx < 4 * NV): a binary tree of selects over scalars (log2 levels, one
@@ -140,10 +171,13 @@ __device__ __forceinline__ int kth_set_bit(M f, int k) {
 // Epsilon-greedy pick from a row held by one lane; same distribution and draw use as select_action
 // (qe_device.h): explore -> k-th valid action, k = mulhi(x1, n_valid); greedy -> k-th action tied at the
 // valid maximum, k = mulhi(x2, n_ties).  Returns -1 when no action is selectable.  `rowm` = masked_row.
+// `nan_max`: some valid column holds a NaN AND the selection follows a NumPy variant of the reference (see
+// select_action): the maximum is NaN, nothing ties with it.
 template <typename T, int NV, typename M>
 __device__ __forceinline__ int select_lane(const RowV<T, NV>& rowm, M valid, bool explore, uint32_t x1,
-                                           uint32_t x2, T* picked) {
-    const T m = row_max_lane(rowm);
+                                           uint32_t x2, T* picked, bool nan_max) {
+    T m = row_max_lane(rowm);
+    if (nan_max) m = quiet_nan<T>();
     M ties = 0;
 #pragma unroll
     for (int j = 0; j < 4 * NV; ++j) ties |= (M)(rowm.v[j] == m ? 1u : 0u) << j;
@@ -306,10 +340,12 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
     if ((QX(6) && worker) || (QX(7) && helper)) return;  // (timing experiments)
 
     // selection + env.step of step t1 from `row` (= Q[p.n]); the new pending transition replaces p
-    auto advance = [&](const RowV<T, NV>& row, M valid, long long t1, const U4& x, unsigned long long thr_t1) {
+    // (`row_nan`: the masked row holds a NaN -- handed in because the quiet path knows it from its update)
+    const bool nan_sel = c.nan_select != 0;
+    auto advance = [&](const RowV<T, NV>& row, M valid, long long t1, const U4& x, unsigned long long thr_t1, bool row_nan) {
         const bool explore = (unsigned long long)x.x < thr_t1;
         T picked;
-        int act = select_lane<T, NV, M>(masked_row<MASKED>(row, valid), valid, explore, x.y, x.z, &picked);
+        int act = select_lane<T, NV, M>(masked_row<MASKED>(row, valid), valid, explore, x.y, x.z, &picked, nan_sel && row_nan);
         if (act < 0) {
             // no selectable action (everything masked, or a NaN row maximum): the reference's
             // random.choice raises IndexError (q_learning_optimal.py:470,563); reported at the end of the
@@ -380,7 +416,8 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
     {   // select(0), env.step(0); rows written in step 0; then the bookkeeping of transition 0
         load_row_lane<NV>(row, c.q, p.n);
         if (active) {
-            advance(row, valid_mask_lane<Env, NV, MASKED>(ev, i, p.n), 0, philox_of(0), c.thr[0]);
+            const M valid0 = valid_mask_lane<Env, NV, MASKED>(ev, i, p.n);
+            advance(row, valid0, 0, philox_of(0), c.thr[0], row_nan_lane<NV>(masked_row<MASKED>(row, valid0)));
             int h = (int)(mix32((uint32_t)p.s) & (WT - 1));
             int old = atomicCAS(&lds.wt[0][h], -1, p.s);
             while (old != -1 && old != p.s) {
@@ -487,11 +524,17 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         const float r_t = p.r;
         const bool term_t = p.term;
         // ---- update of transition t for agents that may go now ----------------------------------
+        // np.max of the row (q_learning_optimal.py:757-761): NaN when a valid column holds one.  After the update the
+        // same flag serves the selection from this row: an own write into it (p.n == p.s) adds a NaN exactly when
+        // the new value is one, and cannot remove one (a NaN in the written cell makes the new value NaN as well).
+        bool row_nan = row_nan_lane<NV>(masked_row<MASKED>(row, valid));
         if (active && (cls & 1)) {
-            const T m = row_max_lane(masked_row<MASKED>(row, valid));
+            T m = row_max_lane(masked_row<MASKED>(row, valid));
+            if (row_nan) m = quiet_nan<T>();
             const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
             T u;
             const T q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), c.mode, &u);
+            if (p.n == p.s) row_nan |= q1 != q1;
             if (!QX(1)) c.q[cell] = q1;
             // delta log of the replica exchange: a running pointer (slot = base + t * N + agent)
             if (dl_ok) *dl = DeltaEntry{(uint32_t)cell, (float)u};
@@ -519,7 +562,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         QL_STAMP(4);
         // (a busy step selects for ALL its agents in one pass, after its ordered updates: executing the
         // selection + env.step code twice per wavefront costs more than the few lanes of the second pass save)
-        if (active && !busy && !last) advance(row, valid, t + 1, x, thr_t1);
+        if (active && !busy && !last) advance(row, valid, t + 1, x, thr_t1, row_nan);
         QL_STAMP(5);
 
         if (busy) {
@@ -553,7 +596,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
                             if (!p.term) {
                                 RowV<T, NV> fresh;
                                 load_row_lane<NV>(fresh, c.q, p.n);
-                                m = row_max_lane(masked_row<MASKED>(fresh, valid));
+                                m = row_max_np_lane<T, NV>(masked_row<MASKED>(fresh, valid));
                             }
                             const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
                             const T q0 = c.q[cell];
@@ -624,7 +667,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
                             if (!p.term) {
                                 RowV<T, NV> fresh;
                                 load_row_lane<NV>(fresh, c.q, p.n);
-                                m = row_max_lane(masked_row<MASKED>(fresh, valid));
+                                m = row_max_np_lane<T, NV>(masked_row<MASKED>(fresh, valid));
                             }
                             const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
                             const T q0 = c.q[cell];
@@ -645,7 +688,7 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
             // state that move on to the same successor: the row gathered before the step is still the row)
             if (active && !last) {
                 if (cls != 3 && !((cls & 2) && p.n != p.s)) load_row_lane<NV>(row, c.q, p.n);
-                advance(row, valid, t + 1, x, thr_t1);
+                advance(row, valid, t + 1, x, thr_t1, row_nan_lane<NV>(masked_row<MASKED>(row, valid)));
             }
             if (tid == 0) { lds.n_def = 0u; lds.complex_ = 0u; }
             __builtin_amdgcn_s_waitcnt(0x0F70);  // (busy step: nothing in flight on any path, see above)

@@ -152,9 +152,13 @@ int qe_set_agent_offset(qe_engine* e, uint32_t offset); /* draw-protocol id of l
  * `deterministic`: bit 0 = greedy selection (exploration rate ignored); bit 1 (QE_SELECT_NUMPY_EMPTY_MASK)
  * = the NumPy variants' treatment of an agent whose mask has no valid action: its greedy pick is
  * uniform over ALL actions (where(mask, Q, -inf) ties everywhere, :497-503, :618-628), only its
- * exploratory pick is impossible (-1; the reference raises IndexError, :470).  Consumes one step index. */
+ * exploratory pick is impossible (-1; the reference raises IndexError, :470); bit 2 (QE_SELECT_NUMPY_MAX) = the row
+ * maximum is np.max (the NumPy variants, :428, :466, :548, :616): NaN as soon as a valid column holds one, so no
+ * action ties with it (-1; the reference raises IndexError) -- without it the list variants' scan, which steps
+ * over NaN columns (:290-296, :337-344).  Consumes one step index. */
 #define QE_SELECT_DETERMINISTIC 1
 #define QE_SELECT_NUMPY_EMPTY_MASK 2
+#define QE_SELECT_NUMPY_MAX 4
 int qe_choose_actions(qe_engine* e, const int32_t* states, int64_t n, const uint8_t* masks,
                       double exploration_rate, int32_t deterministic, int32_t* out_actions);
 

@@ -69,9 +69,14 @@ class CHashRollout:
         es, ea = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
         er = np.empty(cap, dtype=np.float32)
         cnt = C.c_int64(0)
-        self.lib.oc_rollout(C.byref(self.cfg), _p(self.q), _p(self.obs), _p(self.episode), _p(self.acc),
-                            C.c_uint64(self.step), C.c_int64(steps), _p(eps), _p(lr), _p(tr), _p(es), _p(ea),
-                            _p(er), C.c_int64(cap), C.byref(cnt))
+        rc = self.lib.oc_rollout(C.byref(self.cfg), _p(self.q), _p(self.obs), _p(self.episode), _p(self.acc),
+                                 C.c_uint64(self.step), C.c_int64(steps), _p(eps), _p(lr), _p(tr), _p(es), _p(ea),
+                                 _p(er), C.c_int64(cap), C.byref(cnt))
+        if rc:  # like the reference: random.choice on an empty candidate set (q_learning_optimal.py:470, :563)
+            self.step += rc - 1
+            self.failed_step = rc - 1
+            msg = "Cannot choose from an empty sequence"
+            raise IndexError(msg)
         self.step += steps
         k = min(cnt.value, cap)
         out = {"actions": tr, "history": er[:k].copy(), "ep_step": es[:k].copy(), "episodes": cnt.value}

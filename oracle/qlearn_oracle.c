@@ -70,22 +70,30 @@ static unsigned long long eps_threshold(double eps) {
     return v >= 4294967296.0 ? (1ull << 32) : (unsigned long long)v;
 }
 
-/* max over the valid actions of row `obs` (in the table dtype; -inf if none) */
-static double row_max(const oc_cfg* c, const void* q, int32_t obs) {
+/* max over the valid actions of row `obs` (in the table dtype; -inf if none).
+ * np_max != 0: np.max (q_learning_optimal.py:548, :757-761, :884-888) -- NaN as soon as a valid column holds one;
+ * np_max == 0: the scan of the list variants (:290-296, :337-344: `if v > max_val`), which steps over a NaN. */
+static double row_max(const oc_cfg* c, const void* q, int32_t obs, int np_max) {
     double m = -INFINITY;
+    int nan = 0;
     for (int j = 0; j < c->A; ++j)
         if (valid_action(c, obs, j)) {
             const double v = q_at(c, q, (int64_t)obs * c->A + j);
             if (v > m) m = v;
+            nan |= v != v;
         }
-    return m;
+    return (np_max && nan) ? (double)NAN : m;
 }
+
+/* Which family of selection variants the reference's dispatcher (:644-726, thresholds :14-20) runs for a training
+ * step at this shape: list variants (n < 100 unmasked, A <= 10 masked) or NumPy variants. */
+static int numpy_selection(const oc_cfg* c) { return c->masked ? c->A > 10 : c->n >= 100; }
 
 static int select_action(const oc_cfg* c, const void* q, int i, int32_t obs, uint64_t step, unsigned long long thr) {
     uint32_t x[4] = {c->agent_offset + (uint32_t)i, (uint32_t)step, (uint32_t)(step >> 32), 0u};
     philox4x32_10(x, (uint32_t)c->seed, (uint32_t)(c->seed >> 32));
     const int explore = (unsigned long long)x[0] < thr;
-    const double m = explore ? 0.0 : row_max(c, q, obs);
+    const double m = explore ? 0.0 : row_max(c, q, obs, numpy_selection(c));
     int total = 0;
     for (int j = 0; j < c->A; ++j)
         total += valid_action(c, obs, j) && (explore || q_at(c, q, (int64_t)obs * c->A + j) == m);
@@ -144,7 +152,9 @@ static double td_vec_inc(const oc_cfg* c, const void* q, int64_t cell, float r, 
 }
 
 /* Runs `steps` vector steps.  obs / episode / acc are the env + bookkeeping state (in/out).
- * trace (steps*n) and the episode log are optional (NULL / cap 0).  Returns 0. */
+ * trace (steps*n) and the episode log are optional (NULL / cap 0).  Returns 0, or t + 1 when the selection of
+ * vector step t had no candidate under a NumPy variant (the reference raises IndexError there; the state is
+ * left as it was before that step). */
 int oc_rollout(const oc_cfg* c, void* q, int32_t* obs, uint32_t* episode, float* acc, uint64_t step0,
                int64_t steps, const double* eps, const double* lr, int32_t* trace, int32_t* ep_step,
                int32_t* ep_agent, float* ep_ret, int64_t ep_cap, int64_t* ep_count) {
@@ -158,6 +168,15 @@ int oc_rollout(const oc_cfg* c, void* q, int32_t* obs, uint32_t* episode, float*
     for (int64_t t = 0; t < steps; ++t) {
         const unsigned long long thr = eps_threshold(eps[t]);
         for (int i = 0; i < n; ++i) act[i] = select_action(c, q, i, obs[i], step0 + (uint64_t)t, thr);
+        if (numpy_selection(c)) { /* random.choice([]) raises IndexError (:470, :563): the run ends at this step */
+            int empty = 0;
+            for (int i = 0; i < n; ++i) empty |= act[i] < 0;
+            if (empty) {
+                if (ep_count) *ep_count = neps;
+                free(act); free(nxt); free(rew); free(term); free(inc);
+                return (int)(t + 1);
+            }
+        }
         if (trace) memcpy(trace + t * n, act, sizeof(int32_t) * n);
         for (int i = 0; i < n; ++i) { /* env.step with SAME_STEP autoreset */
             const uint32_t key = (uint32_t)obs[i] * (uint32_t)c->A + (uint32_t)act[i];
@@ -169,12 +188,12 @@ int oc_rollout(const oc_cfg* c, void* q, int32_t* obs, uint32_t* episode, float*
         }
         if (c->mode == 0) {
             for (int i = 0; i < n; ++i) {
-                const double m = term[i] ? 0.0 : row_max(c, q, nxt[i]);
+                const double m = term[i] ? 0.0 : row_max(c, q, nxt[i], 1);
                 td_iter(c, q, (int64_t)obs[i] * c->A + act[i], rew[i], m, term[i], lr[t]);
             }
         } else {
             for (int i = 0; i < n; ++i)
-                inc[i] = td_vec_inc(c, q, (int64_t)obs[i] * c->A + act[i], rew[i], row_max(c, q, nxt[i]), term[i], lr[t]);
+                inc[i] = td_vec_inc(c, q, (int64_t)obs[i] * c->A + act[i], rew[i], row_max(c, q, nxt[i], 1), term[i], lr[t]);
             for (int i = 0; i < n; ++i) { /* np.add.at: float64 add, rounded into the table dtype */
                 const int64_t cell = (int64_t)obs[i] * c->A + act[i];
                 dlog_put(cell, (float)inc[i]);

@@ -167,6 +167,10 @@ def _schedules(kind):
         return ExponentialSchedule(0.1, 1e-5, 0.995), ExponentialSchedule(1.0, 0.01, 0.995)
     if kind == "const":
         return ConstantSchedule(0.1), ConstantSchedule(0.1)
+    if kind == "nan":  # diverging (tests/helpers.py:schedule_params)
+        return ConstantSchedule(1.0), ConstantSchedule(0.3)
+    if kind == "explore":
+        return ConstantSchedule(0.25), ConstantSchedule(1.0)
     return ConstantSchedule(1.0), LinearSchedule(0.05, 0.001)  # "kat"
 
 

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from helpers import GOLDEN, TRACE_CASES, dense_from_sparse, run_oracle_trace, schedule_params
-from golden.make_golden_cases import LEARN_CASES, SELECT_CASES
+from golden.make_golden_cases import LEARN_CASES, SCALE_TRACE_CASES, SELECT_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -289,6 +289,27 @@ def test_rollout_matches_reference_golden(name, path):
     assert np.array_equal(got["final_obs"], g[f"{name}/final_obs"])
     assert np.array_equal(got["agent_rewards"], g[f"{name}/agent_rewards"])
     assert np.array_equal(got["final_sched"], g[f"{name}/final_sched"])
+
+
+@pytest.mark.parametrize("path", ["stepwise", "wide", "wide_listed", "turnstile", "turnstile_reread", "auto"])
+@pytest.mark.parametrize("case", SCALE_TRACE_CASES, ids=[c[0] for c in SCALE_TRACE_CASES])
+def test_rollout_matches_reference_golden_at_scale(case, path):
+    """SURVEY 8(c)'s "shrunk C3" (4096 agents on the 1e6 x 16 table: the turnstile path's chains of row sharers) and
+    "C5-small" (1024 masked agents, 64 actions), generated from the REAL reference (tests/golden/make_golden_r3.py)."""
+    name, spec, steps, dt, sched, learn_fn = case
+    g = np.load(GOLDEN / "traces_scale.npz")
+    got = _run_product_trace(spec, steps, dt, sched, "iter" if learn_fn == "learn" else "vec", path=path)
+    assert np.array_equal(got["actions"], g[f"{name}/actions"].astype(np.int32))
+    idx = np.cumsum(g[f"{name}/q_idx_delta"].astype(np.int64))
+    want_q = dense_from_sparse(idx, g[f"{name}/q_val"], got["q"].shape, got["q"].dtype)
+    assert np.array_equal(got["q"], want_q)
+    assert np.array_equal(got["history"], g[f"{name}/history"])
+    assert np.array_equal(got["final_obs"], g[f"{name}/final_obs"])
+    assert np.array_equal(got["agent_rewards"], g[f"{name}/agent_rewards"])
+    assert np.array_equal(got["final_sched"], g[f"{name}/final_sched"])
+    if path in ("turnstile", "auto"):
+        from dist_classicrl_amd import _lib
+        assert _lib.decode_variant(got["stats"]["kernel_variant"])["path"] == "turnstile"
 
 
 @pytest.mark.parametrize(

@@ -173,22 +173,28 @@ def test_delta_log_builds_record_every_action_and_increment(n, S, A, steps, call
     """LEAN = 2 (the builds a replica runs: same loop + one {cell, delta} record per agent-step).  The log is the
     action trace these builds can give: cell = s * ld + a of EVERY agent-step and the float32 increment it applied must
     equal the C oracle's, so actions are checked step by step on a LEAN build, not only through the final table."""
-    torch = pytest.importorskip("torch")
     _lib, Algo, Runtime, envs, sch = _product()
     lib = _lib.load()
     algo = Algo(S, A, 0.99, seed=0)
     algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, ordered_path)
-    log = torch.zeros((steps * n, 2), dtype=torch.int32, device="cuda:0")
-    _lib.check(lib.qe_delta_log_attach(algo.handle, C.c_void_p(log.data_ptr()), steps * n))
-    torch.cuda.synchronize()
+    # the caller-owned log buffer: plain device memory from the HIP runtime the engine itself is linked against
+    # (torch brings a runtime of its own, which sees no GPU once the engine's has initialised in this process)
+    hip = C.CDLL("libamdhip64.so")
+    log_dev, nbytes = C.c_void_p(), steps * n * 8
+    assert hip.hipMalloc(C.byref(log_dev), C.c_size_t(nbytes)) == 0
+    assert hip.hipMemset(log_dev, 0, C.c_size_t(nbytes)) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    _lib.check(lib.qe_delta_log_attach(algo.handle, log_dev, steps * n))
     rt = _bench_runtime(algo, sch, Runtime)
     history, sd, variants, _ = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), _split(steps, call))
     full = n % 64 == 0
     _assert_lane_build(_lib, variants, lean=2, light=ordered_path == 1 and full, full=full, nv=A // 4)
     _lib.check(lib.qe_synchronize(algo.handle))
     assert lib.qe_delta_log_count(algo.handle) == steps * n
-    got = log.cpu().numpy()
+    got = np.empty((steps * n, 2), dtype=np.int32)
+    assert hip.hipMemcpy(got.ctypes.data_as(C.c_void_p), log_dev, C.c_size_t(nbytes), 2) == 0  # hipMemcpyDeviceToHost
     _lib.check(lib.qe_delta_log_attach(algo.handle, None, 0))
+    assert hip.hipFree(log_dev) == 0
     ref, want = _c_oracle_run(n, S, A, steps, delta_log=True)
     ld = int(lib.qe_table_row_stride(algo.handle))
     cells = got[:, 0].view(np.uint32)
