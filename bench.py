@@ -143,6 +143,9 @@ def main() -> None:
     ap.add_argument("--turn-forward", type=int, default=1, choices=[0, 1],
                     help="turnstile path (513 .. ~60 000 agents): 0 = no value forwarding in the progress words "
                          "(measurement switch, results are identical)")
+    ap.add_argument("--lane-ordered-path", type=int, default=0, choices=[0, 1, 2],
+                    help="persistent path, up to 128 agents: 0 = automatic, 1 = the dataflow kernel, 2 = the build with the "
+                         "general ordered path (measurement switch, results are identical)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the ranks; gloo + fewer GPUs than ranks (ranks then share GPUs) is a "
                          "rehearsal of the N > 1 path on a small box, not a measurement")
@@ -200,6 +203,8 @@ def main() -> None:
                              ExponentialSchedule(1.0, 0.01, 0.995), learn_mode=args.mode)
     if not args.turn_forward:
         algo.set_engine_option(_lib.OPT_TURN_FORWARD, 0)
+    if args.lane_ordered_path:
+        algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, args.lane_ordered_path)
     if n >= 16384:
         # hundreds of thousands of episodes end per call: take the returns as one float32 array
         # instead of a Python list with one object per episode (the values are the same)

@@ -40,7 +40,7 @@ def decode_variant(v: int) -> dict:
     return {
         "path": {1: "stepwise", 2: "persistent", 3: "wide", 4: "turnstile", 5: "eval"}.get(v & 15, "none"),
         "lean": (v >> 4) & 3, "help": bool((v >> 6) & 1), "full": bool((v >> 7) & 1), "light": bool((v >> 8) & 1),
-        "cap512": bool((v >> 9) & 1), "nv": (v >> 12) & 255, "masked": bool((v >> 20) & 1),
+        "cap512": bool((v >> 9) & 1), "dataflow": bool((v >> 10) & 1), "nv": (v >> 12) & 255, "masked": bool((v >> 20) & 1),
     }
 
 

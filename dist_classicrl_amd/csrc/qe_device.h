@@ -250,7 +250,7 @@ __device__ __forceinline__ uint32_t in_range4(int sub, int A) {
 // Epsilon-greedy pick (all reference choose_action* variants share this distribution,
 // q_learning_optimal.py:263-642): explore -> k-th valid action, k = mulhi(x1, n_valid);
 // greedy -> k-th action tied at the valid maximum, k = mulhi(x2, n_ties).  Returns -1 when no
-// action is selectable.  *picked_q receives Q[s, action] as held in `row`.
+// action is selectable (-2: because the maximum is NaN).  *picked_q receives Q[s, action] as held in `row`.
 // `nan_max`: the row maximum is NumPy's (NaN when a valid column holds one: nothing ties with it, no greedy pick is
 // possible and the reference's random.choice raises, :430, :470, :563, :628) -- the NumPy variants; false = the
 // list variants' scan, which steps over NaN columns (:290-296, :337-344).
@@ -308,6 +308,9 @@ __device__ __forceinline__ int select_action(const Row4<T>& row, uint32_t valid4
         }
     }
     act = group_max_int<LC>(act, L);
+    // (NaN maximum: "no candidate" of a different kind than an empty / all -inf candidate set, which the NumPy
+    // variants tie everywhere -- callers that implement that quirk must tell the two apart)
+    if (m != m && !explore) act = -2;
     const int jj = act & 3;
     const T mine = jj == 0 ? row.v[0] : (jj == 1 ? row.v[1] : (jj == 2 ? row.v[2] : row.v[3]));
     const int holder = act < 0 ? 0 : (act >> 2);

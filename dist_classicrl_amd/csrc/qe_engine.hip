@@ -379,11 +379,16 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         ms = (float)(e->ms_per_step_est * (double)sl.steps);
     }
     if (sl.persistent && sl.steps > 0) {
-        // Which build of the persistent kernel the NEXT launches take (see SEQ in qe_rollout_lane.h): the full one
-        // as soon as more than 1 % of a launch's steps needed the general ordered path, the light one again after
-        // a launch of some length without any.
-        if ((double)fin.pending_total > 0.01 * (double)sl.steps) e->lane_light = 0;
-        else if (fin.pending_total == 0 && sl.steps >= 64) e->lane_light = 1;
+        // Which build of the persistent kernel the NEXT launches of up to 128 agents take: the dataflow kernel
+        // (qe_rollout_df.h; it reports its dataflow rounds beyond the first of a step) unless those ran long -- deep
+        // chains of row sharers, e.g. a hundred agents on one state, are what k_rollout_lane's ordered path
+        // (slow_body, run-ahead along same-cell chains) is for; that one reports the steps which needed it, and a
+        // launch of some length without any hands the next ones back to the dataflow kernel.
+        if (sl.variant & QE_VARIANT_DATAFLOW) {
+            if ((double)fin.pending_total > 16.0 * (double)sl.steps) e->lane_light = 0;
+        } else if (fin.pending_total == 0 && sl.steps >= 64) {
+            e->lane_light = 1;
+        }
     }
     if (sl.wide && sl.steps > 0) {
         // Number of chip-wide token rounds of the NEXT calls: every round roughly halves the agents that

@@ -42,6 +42,9 @@ __device__ __forceinline__ uint32_t valid4_from_words(WordFn word, int sub, int 
 
 // ---- HostEnv: no dynamics; masks (if any) come from the caller (qe_choose_actions / qe_learn) --
 struct HostEnv {
+    // two agents that take the same action in the same state in one step see the same reward, termination flag
+    // and (unless it terminates) successor: no dynamics
+    static constexpr bool kSameOutcome = false;
     static __device__ __forceinline__ uint32_t valid4(const EnvCtx& ev, int64_t agent, int32_t,
                                                       int sub) {
         if (!ev.masked) return in_range4(sub, ev.A);
@@ -57,6 +60,9 @@ struct HostEnv {
 
 // ---- HashTabularEnv (oracle/envs.py:HashTabularEnv) ---------------------------------------------
 struct HashEnv {
+    // two agents that take the same action in the same state in one step see the same reward, termination flag
+    // and (unless it terminates) successor: reward, termination and successor are functions of (state, action)
+    static constexpr bool kSameOutcome = true;
     static __device__ __forceinline__ int32_t start_state(const EnvCtx& ev, int64_t agent,
                                                           uint32_t episode) {
         // two murmur finaliser rounds over (agent, episode, seed): ~15 ALU ops on the reset path of a
@@ -99,6 +105,9 @@ struct HashEnv {
 
 // ---- GridLakeEnv (oracle/envs.py:GridLakeEnv) ---------------------------------------------------
 struct GridEnv {
+    // two agents that take the same action in the same state in one step see the same reward, termination flag
+    // and (unless it terminates) successor: deterministic moves
+    static constexpr bool kSameOutcome = true;
     static __device__ __forceinline__ uint32_t valid4(const EnvCtx& ev, int64_t, int32_t, int sub) {
         return in_range4(sub, ev.A);
     }
@@ -127,6 +136,9 @@ struct GridEnv {
 
 // ---- Rigged two-armed bandit (environments/rigged_two_armed_bandit.py:55-80) --------------------
 struct BanditEnv {
+    // two agents that take the same action in the same state in one step see the same reward, termination flag
+    // and (unless it terminates) successor: the reward depends on the agent's position in its episode
+    static constexpr bool kSameOutcome = false;
     static __device__ __forceinline__ uint32_t valid4(const EnvCtx& ev, int64_t, int32_t, int sub) {
         return in_range4(sub, ev.A);
     }
@@ -156,6 +168,9 @@ constexpr uint32_t C_TTT = 0x7F4A7C15u;
 constexpr unsigned long long TTT_RESET_STEP = 0xFFFFFFFFFFFFFFFFull;
 
 struct TttEnv {
+    // two agents that take the same action in the same state in one step see the same reward, termination flag
+    // and (unless it terminates) successor: the opponent's reply is drawn per agent and step
+    static constexpr bool kSameOutcome = false;
     static __device__ __forceinline__ bool wins(uint32_t m) {
         return (m & 0007) == 0007 || (m & 0070) == 0070 || (m & 0700) == 0700 || (m & 0111) == 0111 ||
                (m & 0222) == 0222 || (m & 0444) == 0444 || (m & 0421) == 0421 || (m & 0124) == 0124;

@@ -313,7 +313,9 @@ constexpr int GRAPH_STEPS = 50;  // vector steps per captured graph (step-wise /
 //              4 turnstile (k_step_turn), 5 greedy evaluation (k_eval)
 //   persistent path only: bits 4-5 LEAN (0 generic, 1 plain training rollout, 2 + delta log), bit 6 HELP (draw-producing
 //   wavefronts), bit 7 FULL (every lane an agent), bit 8 SEQ (built without the general ordered path), bit 9 the
-//   512-agent build, bits 12-19 NV (16-byte loads per fp32 row), bit 20 masked environment
+//   512-agent build, bit 10 the dataflow kernel (k_rollout_df), bits 12-19 NV (16-byte loads per fp32 row), bit 20
+//   masked environment
+constexpr int64_t QE_VARIANT_DATAFLOW = 1 << 10;  // persistent path: k_rollout_df (qe_rollout_df.h)
 constexpr int64_t QE_VARIANT_STEPWISE = 1, QE_VARIANT_PERSISTENT = 2, QE_VARIANT_WIDE = 3, QE_VARIANT_TURNSTILE = 4,
                   QE_VARIANT_EVAL = 5;
 template <typename T, class Env>

@@ -1,6 +1,7 @@
 // qe_inst_lane.hip -- persistent path: the k_rollout_lane instantiations of ONE (table dtype, environment) pair.
 // Compiled once per pair (-DQE_INST_T=... -DQE_INST_ENV=...), see Makefile; qe_engine.hip calls launch_persistent.
 #include "qe_host.h"
+#include "qe_rollout_df.h"
 
 #if !defined(QE_INST_T) || !defined(QE_INST_ENV)
 #error "compile with -DQE_INST_T=<float|double> -DQE_INST_ENV=<HashEnv|GridEnv|BanditEnv|TttEnv>"
@@ -30,10 +31,9 @@ int launch_persistent(qe_engine* e, qe_env* env, RolloutSlot& sl, const Ctx<T>& 
                                   ((std::is_same<Env, HashEnv>::value && !MK && (NV == 2 || NV == 4)) ||
                                    std::is_same<Env, TttEnv>::value);
         const bool full = (int64_t)block == env->N;  // every lane of the agents' wavefronts holds an agent
-        // The build without the general ordered path (SEQ, see the kernel) where steps with more than two
-        // touchers on a row are rare: expected from the shape at first (agents^2 / states), from the
-        // previous launch's count afterwards.
-        if (e->lane_light < 0) e->lane_light = (double)env->N * (double)env->N < 0.1 * (double)e->S ? 1 : 0;
+        // The dataflow kernel ("light": no general ordered path) unless its rounds ran long in the previous launch
+        // (deep chains of sharers: hundreds of agents on a handful of states), see rollout_end.
+        if (e->lane_light < 0) e->lane_light = 1;
         const bool light = e->opt_lane_ordered == 1 || (e->opt_lane_ordered == 0 && e->lane_light == 1);
         auto launch = [&](auto cap, auto lean_c, auto help, auto full_c, auto seq, unsigned threads) {
             constexpr int CAP = decltype(cap)::value, LEAN = decltype(lean_c)::value;
@@ -41,6 +41,17 @@ int launch_persistent(qe_engine* e, qe_env* env, RolloutSlot& sl, const Ctx<T>& 
             hipLaunchKernelGGL((k_rollout_lane<T, Env, NV, CAP, MK, LEAN, HELP, FULL, SEQ>), dim3(1), dim3(threads), 0, e->stream,
                                sl.sched, c, ev, (long long)steps, flags);
             sl.variant = lane_variant<NV, CAP, MK, LEAN, HELP, FULL, SEQ>();
+        };
+        // plain training rollouts of up to 128 agents without the general ordered path: the dataflow kernel
+        // (qe_rollout_df.h), which orders the sharers of a row by value hand-over in LDS
+        auto launch_df = [&](auto lean_c, auto full_c) {
+            constexpr int LEAN = decltype(lean_c)::value;
+            constexpr bool FULL = decltype(full_c)::value;
+            if constexpr (LEAN != 0) {
+                hipLaunchKernelGGL((k_rollout_df<T, Env, NV, MK, LEAN, FULL>), dim3(1), dim3(2 * block), 0, e->stream,
+                                   sl.sched, c, ev, (long long)steps, flags);
+                sl.variant = lane_variant<NV, 128, MK, LEAN, true, FULL, true>() | QE_VARIANT_DATAFLOW;
+            }
         };
         using I128 = std::integral_constant<int, 128>;
         using I512 = std::integral_constant<int, LANE_MAX_AGENTS>;
@@ -50,8 +61,10 @@ int launch_persistent(qe_engine* e, qe_env* env, RolloutSlot& sl, const Ctx<T>& 
         using Y = std::integral_constant<bool, HAS_LEAN>;
         using N = std::false_type;
         // (light: no wavefronts beyond the agents' and the draw producers' -- the others only serve the general ordered path)
-        if (HAS_LEAN && lean && block <= 128 && !c.dlog && full && light) launch(I128{}, L1{}, Y{}, Y{}, Y{}, 2 * block);
-        else if (HAS_LEAN && lean && block <= 128 && full && light) launch(I128{}, L2{}, Y{}, Y{}, Y{}, 2 * block);  // + delta log of the replica exchange
+        if (HAS_LEAN && lean && block <= 128 && !c.dlog && full && light) launch_df(L1{}, Y{});
+        else if (HAS_LEAN && lean && block <= 128 && full && light) launch_df(L2{}, Y{});  // + delta log of the replica exchange
+        else if (HAS_LEAN && lean && block <= 128 && !c.dlog && light) launch_df(L1{}, N{});
+        else if (HAS_LEAN && lean && block <= 128 && light) launch_df(L2{}, N{});
         else if (HAS_LEAN && lean && block <= 128 && !c.dlog && full) launch(I128{}, L1{}, Y{}, Y{}, N{}, std::max(512u, 2 * block));
         else if (HAS_LEAN && lean && block <= 128 && !c.dlog) launch(I128{}, L1{}, Y{}, N{}, N{}, std::max(512u, 2 * block));
         else if (HAS_LEAN && lean && block <= 128 && full) launch(I128{}, L2{}, Y{}, Y{}, N{}, std::max(512u, 2 * block));

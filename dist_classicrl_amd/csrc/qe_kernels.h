@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_select(Ctx<T> c, EnvCtx ev, cons
     int act = select_action(row, valid, sub, c.L, explore, x.y, x.z, &picked, (deterministic & 4) != 0);
     // NumPy variants of the reference, agent without a valid action: where(mask, Q, -inf) is all -inf, so
     // every action ties at the maximum and the greedy pick is uniform over ALL actions (:497-503, :618-628)
-    if (act < 0 && (deterministic & 2) && ev.masked && !explore) act = (int)mulhi32(x.z, (uint32_t)c.A);
+    if (act == -1 && (deterministic & 2) && ev.masked && !explore) act = (int)mulhi32(x.z, (uint32_t)c.A);
     if (sub == 0) out[i] = act;
 }
 
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_select_large(Ctx<T> c, EnvCtx ev
             k -= cnt;
         }
     }
-    if (act < 0 && (deterministic & 2) && mw != nullptr && !explore) act = (int)mulhi32(x.z, (uint32_t)c.A);  // see k_select
+    if (act < 0 && (deterministic & 2) && mw != nullptr && !explore && m == m) act = (int)mulhi32(x.z, (uint32_t)c.A);  // see k_select
     if (lane == 0) out[i] = act;
 }
 

@@ -87,9 +87,10 @@ typedef struct qe_rollout_stats {
                                 5 evaluation; persistent path: bits 4-5 LEAN (0 generic build, 1 plain training rollout,
                                 2 the same with the delta log), bit 6 draw-producing helper wavefronts, bit 7 every lane an
                                 agent, bit 8 built without the general ordered path ("light"), bit 9 the 512-agent build,
+                                bit 10 the dataflow kernel (sharers of a row ordered by value hand-over in LDS),
                                 bits 12-19 16-byte loads per row, bit 20 masked environment (tests assert on these) */
-    int64_t complex_steps;   /* persistent path: vector steps in which some contested row had more than two touchers (the
-                                steps the "light" build works off one deferred agent per round) */
+    int64_t complex_steps;   /* persistent path: vector steps that needed the general ordered path (full build); the
+                                dataflow kernel reports its dataflow rounds beyond the first of a step instead */
 } qe_rollout_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------
@@ -116,9 +117,9 @@ enum qe_option { QE_OPT_ROLLOUT_PATH = 0, QE_OPT_USE_GRAPH = 1 /* 1 (default): r
                  QE_OPT_HOST_BLOCK = 5 /* 1 (default): a persistent rollout writes its results (control words, final observations,
                                           episode log) into page-locked host memory itself and qe_rollout_end spins on a sequence
                                           word there; 0: stream synchronisation + copies */,
-                 QE_OPT_LANE_ORDERED_PATH = 6 /* persistent kernel, up to 128 agents: 0 (default) = automatic, 1 = the build without the
-                                                 general ordered path (steps with more than two touchers on a row are worked off one
-                                                 agent per round), 2 = the build with it */,
+                 QE_OPT_LANE_ORDERED_PATH = 6 /* persistent path, plain training rollouts of up to 128 agents: 0 (default) = automatic,
+                                                 1 = the dataflow kernel (no general ordered path: sharers of a row hand their
+                                                 values on in LDS), 2 = the build with the general ordered path */,
                  QE_OPT_TURN_FORWARD = 7 /* turnstile path, fp32 tables: 1 (default) = a row's progress word carries the value its last
                                             writer stored, successors whose view of the row can differ in that one column only take it
                                             from their poll; 0 = they always re-read the table (measurement switch) */ };

@@ -2,9 +2,10 @@
 
 Every closed-loop comparison of ``test_gpu_parity.py`` collects an action trace, and a traced rollout of up to
 512 agents runs the generic build of the persistent kernel (``k_rollout_lane<..., 512, MK, 0, false, false>``).
-Plain training rollouts of up to 128 agents take other instantiations of that kernel (``LEAN`` 1 / 2, ``HELP``
-draw-producing wavefronts, ``FULL`` wavefronts, ``SEQ`` = the "light" build without the general ordered path:
-``csrc/qe_inst_lane.hip``) -- different functions with different register allocation.  Here those builds are
+Plain training rollouts of up to 128 agents take other kernels: the dataflow kernel ``k_rollout_df``
+(``csrc/qe_rollout_df.h``: sharers of a row hand their values on in LDS; "light" = no general ordered path) or
+instantiations of ``k_rollout_lane`` with ``LEAN`` 1 / 2, ``HELP`` draw-producing wavefronts and ``FULL`` wavefronts
+(``csrc/qe_inst_lane.hip``) -- different functions with different register allocation.  Here those builds are
 run exactly as a user runs them (no trace; ``qe_rollout_fused`` calls of 20 / 64 / 2000 steps and the pipelined
 ``qe_rollout_begin`` / ``qe_rollout_end`` path) and everything a rollout leaves behind -- the whole Q-table, the
 episode returns in order, the final observations, the running returns -- must equal the oracle bit for bit
@@ -68,6 +69,7 @@ def _assert_lane_build(_lib, variants, *, lean, light, full=True, help_=True, nv
         d = _lib.decode_variant(v)
         assert d["path"] == "persistent", d
         assert d["lean"] == lean and d["help"] == help_ and d["full"] == full and d["light"] == light, d
+        assert d["dataflow"] == light, d  # the builds without the general ordered path are the dataflow kernel
         assert not d["cap512"], d
         if nv is not None:
             assert d["nv"] == nv, d
@@ -94,7 +96,8 @@ def test_plain_training_rollout_builds_match_c_oracle(shape, ordered_path, calls
     history, sd, variants, complex_steps = _run_in_calls(rt, env, plan)
     _assert_lane_build(_lib, variants, lean=1, light=ordered_path == 1, nv=A // 4, masked=False)
     if shape == "c2":
-        assert complex_steps > 0  # rows with more than two touchers: the light build's one-agent-per-round fallback ran
+        # light: dataflow rounds beyond the first (chains of row sharers); full: steps that took the general ordered path
+        assert complex_steps > 0
     ref, want = _c_oracle_run(n, S, A, steps)
     assert np.array_equal(np.asarray(algo.q_table), ref.q)
     assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
@@ -111,8 +114,8 @@ def test_plain_training_rollout_builds_match_c_oracle(shape, ordered_path, calls
     (64, 3000, 16, 300),
 ])
 def test_contested_shapes_through_the_lean_builds(n, S, A, steps, ordered_path):
-    """Forced light / full builds where steps with more than two touchers per row are the rule (the SEQ fallback of
-    the light build, slow_body of the full one) -- no trace."""
+    """Forced dataflow / full builds where steps with several touchers per row are the rule (chains of value
+    hand-overs in the dataflow kernel, slow_body in the full build) -- no trace."""
     _lib, Algo, Runtime, envs, sch = _product()
     algo = Algo(S, A, 0.99, seed=0)
     algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, ordered_path)
@@ -130,13 +133,13 @@ def test_contested_shapes_through_the_lean_builds(n, S, A, steps, ordered_path):
 
 @pytest.mark.parametrize(("n", "S", "A"), [(100, 5000, 16), (37, 900, 8), (1, 50, 16)])
 def test_partly_filled_wavefronts_take_the_lean_build_without_full(n, S, A):
-    """Agent counts that are not a multiple of 64: LEAN = 1, HELP, not FULL, never light."""
+    """Agent counts that are not a multiple of 64 (automatic choice: the dataflow kernel, not FULL)."""
     _lib, Algo, Runtime, envs, sch = _product()
     algo = Algo(S, A, 0.99, seed=0)
     rt = _bench_runtime(algo, sch, Runtime)
     steps = 300
     history, sd, variants, _ = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), _split(steps, 64))
-    _assert_lane_build(_lib, variants, lean=1, light=False, full=False, nv=A // 4)
+    _assert_lane_build(_lib, variants, lean=1, light=True, full=False, nv=A // 4)
     ref, want = _c_oracle_run(n, S, A, steps)
     assert np.array_equal(np.asarray(algo.q_table), ref.q)
     assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
@@ -157,7 +160,7 @@ def test_tictactoe_lean_builds_match_the_oracle(n, ordered_path):
     env = envs.TicTacToeEnv(n, seed=1)
     history, sd, variants, _ = _run_in_calls(rt, env, [25, 35])
     full = n % 64 == 0
-    _assert_lane_build(_lib, variants, lean=1, light=ordered_path == 1 and full, full=full, nv=4, masked=True)
+    _assert_lane_build(_lib, variants, lean=1, light=ordered_path == 1, full=full, nv=4, masked=True)
     want = run_oracle_trace(("ttt", n), steps, "f4", "bench", "iter")
     assert np.array_equal(np.asarray(algo.q_table), want["q"])
     assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
@@ -188,7 +191,7 @@ def test_delta_log_builds_record_every_action_and_increment(n, S, A, steps, call
     rt = _bench_runtime(algo, sch, Runtime)
     history, sd, variants, _ = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), _split(steps, call))
     full = n % 64 == 0
-    _assert_lane_build(_lib, variants, lean=2, light=ordered_path == 1 and full, full=full, nv=A // 4)
+    _assert_lane_build(_lib, variants, lean=2, light=ordered_path == 1, full=full, nv=A // 4)
     _lib.check(lib.qe_synchronize(algo.handle))
     assert lib.qe_delta_log_count(algo.handle) == steps * n
     got = np.empty((steps * n, 2), dtype=np.int32)
@@ -207,23 +210,25 @@ def test_delta_log_builds_record_every_action_and_increment(n, S, A, steps, call
 
 
 def test_automatic_build_choice_follows_the_contention():
-    """QE_OPT_LANE_ORDERED_PATH = 0: light build while steps with more than two touchers per row are rare, the full
-    build once a launch met many, light again after a launch without any -- results equal the oracle throughout."""
+    """QE_OPT_LANE_ORDERED_PATH = 0: the dataflow kernel, unless its rounds ran long in the launch before (deep chains
+    of row sharers -> the build with the general ordered path); results equal the oracle throughout."""
     _lib, Algo, Runtime, envs, sch = _product()
     n, S, A = 128, 1_000_000, 16
     algo = Algo(S, A, 0.99, seed=0)
     rt = _bench_runtime(algo, sch, Runtime)
     history, sd, variants, _ = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), [100] * 8)
-    assert any(_lib.decode_variant(v)["light"] for v in variants)
+    assert all(_lib.decode_variant(v)["dataflow"] for v in variants)
     ref, want = _c_oracle_run(n, S, A, 800)
     assert np.array_equal(np.asarray(algo.q_table), ref.q)
     assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
-    # dense shape: the first launch counts complex steps, the following ones take the full build
-    n, S, A = 128, 200, 16
+    # 128 agents on TWO states: chains of dozens of sharers per row -- the first launch counts its rounds, the
+    # following ones take the full build
+    n, S, A = 128, 2, 16
     algo = Algo(S, A, 0.99, seed=0)
     rt = _bench_runtime(algo, sch, Runtime)
     history, sd, variants, complex_steps = _run_in_calls(rt, envs.HashTabularEnv(n, S, A, seed=1), [100] * 4)
-    assert complex_steps > 0 and any(not _lib.decode_variant(v)["light"] for v in variants)
+    assert complex_steps > 0
+    assert any(_lib.decode_variant(v)["dataflow"] for v in variants) and any(not _lib.decode_variant(v)["light"] for v in variants)
     ref, want = _c_oracle_run(n, S, A, 400)
     assert np.array_equal(np.asarray(algo.q_table), ref.q)
     assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
