@@ -138,14 +138,15 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--agents", type=int, default=None, help="agents per GPU (default: the workload's)")
+    ap.add_argument("--states", type=int, default=None, help="table rows (default: the workload's; analysis runs only)")
     ap.add_argument("--mode", default="iter", choices=["iter", "vec"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--turn-forward", type=int, default=1, choices=[0, 1],
                     help="turnstile path (513 .. ~60 000 agents): 0 = no value forwarding in the progress words "
                          "(measurement switch, results are identical)")
-    ap.add_argument("--lane-ordered-path", type=int, default=0, choices=[0, 1, 2],
+    ap.add_argument("--lane-ordered-path", type=int, default=0, choices=[0, 1, 2, 3],
                     help="persistent path, up to 128 agents: 0 = automatic, 1 = the dataflow kernel, 2 = the build with the "
-                         "general ordered path (measurement switch, results are identical)")
+                         "general ordered path, 3 = the sparse build (measurement switch, results are identical)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend of the ranks; gloo + fewer GPUs than ranks (ranks then share GPUs) is a "
                          "rehearsal of the N > 1 path on a small box, not a measurement")
@@ -164,6 +165,8 @@ def main() -> None:
     wl = dict(WORKLOADS[args.workload])
     if args.agents:
         wl["agents"] = args.agents
+    if args.states:
+        wl["states"] = args.states
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -384,8 +384,17 @@ int rollout_end(qe_engine* e, RolloutSlot& sl, qe_rollout_stats* st) {
         // chains of row sharers, e.g. a hundred agents on one state, are what k_rollout_lane's ordered path
         // (slow_body, run-ahead along same-cell chains) is for; that one reports the steps which needed it, and a
         // launch of some length without any hands the next ones back to the dataflow kernel.
+        // (fin.pending_total: dataflow kernel = its rounds beyond the first of a step; k_rollout_lane = the steps in
+        // which a contested row had more than two touchers)
         if (sl.variant & QE_VARIANT_DATAFLOW) {
-            if ((double)fin.pending_total > 16.0 * (double)sl.steps) e->lane_light = 0;
+            if ((double)fin.pending_total > 16.0 * (double)sl.steps) e->lane_light = 2;  // deep chains: slow_body
+            // hardly anybody depended on anybody (fewer than one agent in two steps) on a shape whose rows are rarely
+            // shared: the sparse build's quiet step is the shorter one
+            else if (sl.steps >= 64 && (double)fin.involved_total < 0.5 * (double)sl.steps &&
+                     (double)sl.N * (double)sl.N < 0.1 * (double)e->S && sl.N % 64 == 0)
+                e->lane_light = 3;
+        } else if ((sl.variant >> 8) & 1) {  // the sparse build
+            if ((double)fin.pending_total > 0.01 * (double)sl.steps) e->lane_light = 1;  // rows are shared after all
         } else if (fin.pending_total == 0 && sl.steps >= 64) {
             e->lane_light = 1;
         }
@@ -659,7 +668,7 @@ int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_TOKEN_ROUNDS && value >= 0 && value <= MAX_TOKEN_ROUNDS) { e->opt_rounds = (int)value; return QE_OK; }
     if (option == QE_OPT_EVENT_TIMING && (value == 0 || value == 1)) { e->opt_timing = (int)value; return QE_OK; }
     if (option == QE_OPT_HOST_BLOCK && (value == 0 || value == 1)) { e->opt_host_block = (int)value; return QE_OK; }
-    if (option == QE_OPT_LANE_ORDERED_PATH && value >= 0 && value <= 2) { e->opt_lane_ordered = (int)value; return QE_OK; }
+    if (option == QE_OPT_LANE_ORDERED_PATH && value >= 0 && value <= 3) { e->opt_lane_ordered = (int)value; return QE_OK; }
     if (option == QE_OPT_TURN_FORWARD && (value == 0 || value == 1)) { e->opt_turn_forward = (int)value; return QE_OK; }
     return qe_fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }

@@ -31,10 +31,20 @@ int launch_persistent(qe_engine* e, qe_env* env, RolloutSlot& sl, const Ctx<T>& 
                                   ((std::is_same<Env, HashEnv>::value && !MK && (NV == 2 || NV == 4)) ||
                                    std::is_same<Env, TttEnv>::value);
         const bool full = (int64_t)block == env->N;  // every lane of the agents' wavefronts holds an agent
-        // The dataflow kernel ("light": no general ordered path) unless its rounds ran long in the previous launch
-        // (deep chains of sharers: hundreds of agents on a handful of states), see rollout_end.
-        if (e->lane_light < 0) e->lane_light = 1;
-        const bool light = e->opt_lane_ordered == 1 || (e->opt_lane_ordered == 0 && e->lane_light == 1);
+        // Three builds for plain training rollouts of up to 128 agents (QE_OPT_LANE_ORDERED_PATH forces one):
+        //   3 sparse  -- k_rollout_lane without the general ordered path (SEQ): steps with more than two touchers on a
+        //                row are worked off one agent per round; the fastest where rows are rarely shared (the shape
+        //                decides at first: agents^2 / states);
+        //   1 dataflow -- k_rollout_df: the sharers of a row hand their values on in LDS; for shapes where most steps
+        //                have several of them;
+        //   2 full    -- k_rollout_lane with slow_body: deep chains (dozens of agents on one state).
+        // rollout_end moves between them on what the previous launch counted.
+        if (e->lane_light < 0) e->lane_light = (double)env->N * (double)env->N < 0.1 * (double)e->S ? 3 : 1;
+        int choice = e->opt_lane_ordered ? e->opt_lane_ordered : e->lane_light;
+        // (the dataflow kernel's written-rows sets pack {row, owner} into 32 bits: state ids below 2^25)
+        if (choice == 1 && e->S >= DF_MAX_STATES) choice = 2;
+        if (choice == 3 && !full) choice = 1;  // (the sparse build exists for full wavefronts)
+        const bool light = choice == 1, sparse = choice == 3;
         auto launch = [&](auto cap, auto lean_c, auto help, auto full_c, auto seq, unsigned threads) {
             constexpr int CAP = decltype(cap)::value, LEAN = decltype(lean_c)::value;
             constexpr bool HELP = decltype(help)::value, FULL = decltype(full_c)::value, SEQ = decltype(seq)::value;
@@ -61,7 +71,9 @@ int launch_persistent(qe_engine* e, qe_env* env, RolloutSlot& sl, const Ctx<T>& 
         using Y = std::integral_constant<bool, HAS_LEAN>;
         using N = std::false_type;
         // (light: no wavefronts beyond the agents' and the draw producers' -- the others only serve the general ordered path)
-        if (HAS_LEAN && lean && block <= 128 && !c.dlog && full && light) launch_df(L1{}, Y{});
+        if (HAS_LEAN && lean && block <= 128 && !c.dlog && full && sparse) launch(I128{}, L1{}, Y{}, Y{}, Y{}, 2 * block);
+        else if (HAS_LEAN && lean && block <= 128 && full && sparse) launch(I128{}, L2{}, Y{}, Y{}, Y{}, 2 * block);
+        else if (HAS_LEAN && lean && block <= 128 && !c.dlog && full && light) launch_df(L1{}, Y{});
         else if (HAS_LEAN && lean && block <= 128 && full && light) launch_df(L2{}, Y{});  // + delta log of the replica exchange
         else if (HAS_LEAN && lean && block <= 128 && !c.dlog && light) launch_df(L1{}, N{});
         else if (HAS_LEAN && lean && block <= 128 && light) launch_df(L2{}, N{});

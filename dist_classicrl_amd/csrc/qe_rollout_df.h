@@ -38,7 +38,9 @@
 namespace qe {
 
 constexpr int DF_CAP = 128;   // agents: two wavefronts (the masks are 128 bits)
-constexpr int DF_WT = 1024;   // slots of a written-rows set (<= 128 entries each)
+constexpr int DF_WT = 4096;   // slots of a written-rows set (<= 128 entries each: probe sequences stay short)
+constexpr uint32_t DF_EMPTY = 0xFFFFFFFFu;  // free slot; a used one holds {row : 25 | owner : 7}
+constexpr int64_t DF_MAX_STATES = 1ll << 25;
 constexpr int DF_SPIN_LIMIT = 1 << 18;
 constexpr unsigned ERR_DF_TIMEOUT = 5u;
 
@@ -76,8 +78,9 @@ struct DfPub {
 
 template <typename T>
 struct DfLds {
-    int key[4][DF_WT + 1];                        // rows written in step k (mod 4), -1 = free; last = dump slot
-    alignas(16) uint32_t wmask[4][DF_WT + 1][4];  // ... and the agents that write them
+    uint32_t key[4][DF_WT + 1];                   // rows written in step k (mod 4): {row << 7 | owner}, the owner being
+                                                  // the agent that inserted the row first; last = dump slot
+    alignas(16) uint32_t wmask[4][DF_CAP + 1][4]; // ... and the agents that write a row, at its owner's index (last: dump)
     alignas(16) DfPub<T> pub[2][DF_CAP];          // new value of the cell agent i updated in step k (parity)
     unsigned char pub_a[4][DF_CAP];               // column of that cell (action of transition k, mod 4)
     uint32_t draws[2][3][DF_CAP];                 // ring of Philox words x0, x1, x2 per agent (step parity)
@@ -94,29 +97,41 @@ __device__ __forceinline__ M128 lds_mask_load(const uint32_t* p) {
     return M128{((unsigned long long)v.y << 32) | v.x, ((unsigned long long)v.w << 32) | v.z};
 }
 
-// value agent j published for step `stamp - 1`, if it has
+// What agent j published for the step with this stamp, if it has: the new value of its cell and the cell's column.
+// float32 tables: ONE 64-bit LDS word {value : 32 | stamp : 24 | column : 8}; float64: value, then stamp (the column
+// comes from pub_a).  (Relaxed workgroup-scope atomics on the LDS words: plain ds_read / ds_write that the compiler
+// neither caches in a register across polls nor turns into flat accesses with a vector-memory wait -- `volatile` on
+// these pointers did the latter and cost 0.5 us per step.)
 template <typename T>
-__device__ __forceinline__ bool df_pub_read(const DfPub<T>* slot, uint32_t stamp, T* val) {
+__device__ __forceinline__ bool df_pub_read(DfPub<T>* slot, const unsigned char* cols, int j, uint32_t stamp, T* val, int* col) {
     if constexpr (sizeof(T) == 4) {
-        const unsigned long long raw = *reinterpret_cast<const volatile unsigned long long*>(slot);
+        const unsigned long long raw = __hip_atomic_load(reinterpret_cast<unsigned long long*>(slot + j), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
         *val = __uint_as_float((uint32_t)raw);
-        return (uint32_t)(raw >> 32) == stamp;
+        *col = (int)(raw >> 56);
+        return (((uint32_t)(raw >> 32)) & 0xFFFFFFu) == stamp;
     } else {
         // (LDS serves a wavefront's accesses in order: the stamp is read first; the writer stores the value first)
-        const uint32_t s = *reinterpret_cast<const volatile uint32_t*>(&slot->stamp);
+        const uint32_t s = __hip_atomic_load(&slot[j].stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
-        *val = *reinterpret_cast<const volatile T*>(&slot->val);
+        const unsigned long long raw = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&slot[j].val), __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+        *val = __longlong_as_double((long long)raw);
+        *col = (int)cols[j];
         return s == stamp;
     }
 }
 template <typename T>
-__device__ __forceinline__ void df_pub_write(DfPub<T>* slot, uint32_t stamp, T val) {
+__device__ __forceinline__ void df_pub_write(DfPub<T>* slot, uint32_t stamp, T val, int col) {
     if constexpr (sizeof(T) == 4) {
-        *reinterpret_cast<volatile unsigned long long*>(slot) = ((unsigned long long)stamp << 32) | __float_as_uint(val);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot),
+                           ((unsigned long long)(((uint32_t)col << 24) | stamp) << 32) | __float_as_uint(val), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
     } else {
-        *reinterpret_cast<volatile T*>(&slot->val) = val;
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot->val), (unsigned long long)__double_as_longlong(val),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
-        *reinterpret_cast<volatile uint32_t*>(&slot->stamp) = stamp;
+        __hip_atomic_store(&slot->stamp, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -146,12 +161,21 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
     }
     c.mode = 0; c.trace = nullptr; c.rp.s = nullptr;
     if constexpr (LEAN == 1) c.dlog = nullptr;
+#ifdef QE_STAMPS  // (diagnostic build: time per section of the loop, printed with QE_PRINT_STAMPS=1)
+    long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_last = wall_clock64();
+    if (threadIdx.x == 0) for (int k = 8; k < 24; ++k) c.vinc[k] = 0.0;
+#endif
     const int tid = threadIdx.x;
     // agents' wavefronts first, then as many draw-producing wavefronts (see HELP in qe_rollout_lane.h)
     const int n_main = (int)((c.N + 63) & ~63ll);
     const int wave_tid = __builtin_amdgcn_readfirstlane(tid);  // (uniform per wavefront)
     const bool helper = wave_tid >= n_main;
-    const int i = helper ? tid - n_main : tid;
+    // Agents are dealt to the (one or two) wavefronts of agents round robin: agent 2l + w sits in lane l of wavefront w.
+    // Every dependency points to a lower agent index; with agents 0..63 in one wavefront and 64..127 in the other, the
+    // second one's chains would only start when the first one's have ended.
+    const int n_waves = n_main >> 6;
+    const int i = helper ? tid - n_main : (tid & 63) * n_waves + (tid >> 6);
     const bool active = FULL ? !helper : (!helper && i < c.N);
     const int ii = i < c.N ? i : 0;
     Pending<T> p;
@@ -161,12 +185,14 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
     float acc = c.acc[ii];
     unsigned long long dep_total = 0, ep_base = 0;  // agent-steps with a lower-indexed writer on one of their rows
     unsigned extra_rounds = 0;                      // dataflow rounds beyond the first (statistics)
-    int w_next = WT, w_cur = WT, w_prev = WT;  // my entries of the written-rows sets of steps t+1, t, t-1 (dump slot: none)
+    // my entries of the written-rows sets of steps t+1, t, t-1: slot of the key (dump slot: none) and owner of the row
+    int w_next = WT, w_cur = WT, w_prev = WT;
+    int own_next = DF_CAP, own_cur = DF_CAP, own_prev = DF_CAP;
     const int flush_every = 32;  // steps per flush window of the staged episode log
     int flush_in = flush_every;
-    for (int k = tid; k < 4 * (WT + 1); k += (int)blockDim.x) (&lds.key[0][0])[k] = -1;
-    for (int k = tid; k < 4 * (WT + 1) * 4; k += (int)blockDim.x) (&lds.wmask[0][0][0])[k] = 0u;
-    for (int k = tid; k < 2 * DF_CAP; k += (int)blockDim.x) df_pub_write(&lds.pub[0][0] + k, 0u, (T)0);
+    for (int k = tid; k < 4 * (WT + 1); k += (int)blockDim.x) (&lds.key[0][0])[k] = DF_EMPTY;
+    for (int k = tid; k < 4 * (DF_CAP + 1) * 4; k += (int)blockDim.x) (&lds.wmask[0][0][0])[k] = 0u;
+    for (int k = tid; k < 2 * DF_CAP; k += (int)blockDim.x) df_pub_write(&lds.pub[0][0] + k, 0u, (T)0, 0);
     static_assert(sizeof(Ctx<T>) <= sizeof(lds.cold), "context stash too small");
     if (tid == 0) {
         *reinterpret_cast<Ctx<T>*>(lds.cold) = c;
@@ -213,47 +239,53 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
     M128 Ws = my_bit;           // writers of row p.s in step k (always holds my own bit)
     M128 Wn = m128_zero();      // writers of row p.n in step k (kept empty when p.n == p.s: that row is row p.s)
     M128 Wst = m128_zero();     // writers of row p.n in step k - 1: their values bring the gathered row up to date
-    // The bookkeeping of the transition pending in p (step k), ONE LDS round trip in the common case (plus one more
-    // per round of linear probing past slots held by other rows; the probe sequences advance side by side):
-    //   insert  p.n into set k+1 (p.n is the row I write in step k+1) and my bit into its writers
+    // The bookkeeping of the transition pending in p (step k), ONE LDS round trip in the common case (plus one more per
+    // round of linear probing past slots held by other rows -- the probe sequences advance side by side -- and one
+    // when the row I read has writers):
+    //   insert  p.n into set k+1 (p.n is the row I write in step k+1; the first to insert a row owns its writers' mask)
+    //           and my bit into its writers
     //   look up p.n in set k     (rows written in step k)   -> Wn
     //   look up p.n in set k-1   (rows written in step k-1) -> Wst (k == 0: nothing was written before)
-    //   my own entry of set k                               -> Ws
+    //   the mask of my own entry of set k                   -> Ws
     auto bookkeeping = [&](long long k, bool first) {
-        int* const key_w = lds.key[(k + 1) & 3];
-        const int* const key_r = lds.key[k & 3];
-        const int* const key_st = lds.key[(k + 3) & 3];
-        const uint32_t(*const mask_r)[4] = lds.wmask[k & 3];
-        const uint32_t(*const mask_st)[4] = lds.wmask[(k + 3) & 3];
-        const int32_t rowid = p.n;
-        const int h = (int)(mix32((uint32_t)rowid) & (WT - 1));
-        const bool need_r = rowid != p.s;
-        int o_w = atomicCAS(&key_w[h], -1, rowid);
-        int k_r = need_r ? key_r[h] : -1;
-        int k_st = first ? -1 : key_st[h];
-        M128 m_r = lds_mask_load(mask_r[h]);      // (speculative: valid if the key at h is mine)
-        M128 m_st = lds_mask_load(mask_st[h]);
-        Ws = lds_mask_load(mask_r[w_next]);       // w_next: my slot in set k (it becomes w_cur below)
+        uint32_t* const key_w = lds.key[(k + 1) & 3];
+        const uint32_t* const key_r = lds.key[k & 3];
+        const uint32_t* const key_st = lds.key[(k + 3) & 3];
+        const uint32_t rowid = (uint32_t)p.n;
+        const uint32_t mine = (rowid << 7) | (uint32_t)ii;
+        const int h = (int)(mix32(rowid) & (WT - 1));
+        const bool need_r = p.n != p.s;
+        uint32_t o_w = atomicCAS(&key_w[h], DF_EMPTY, mine);
+        uint32_t k_r = need_r ? key_r[h] : DF_EMPTY;
+        uint32_t k_st = first ? DF_EMPTY : key_st[h];
+        Ws = lds_mask_load(lds.wmask[k & 3][own_next]);  // own_next: the owner of my row in set k (becomes own_cur below)
         int h_w = h, h_r = h, h_st = h;
-        bool odd_w = o_w != -1 && o_w != rowid, odd_r = k_r != -1 && k_r != rowid, odd_st = k_st != -1 && k_st != rowid;
+        bool odd_w = o_w != DF_EMPTY && (o_w >> 7) != rowid, odd_r = k_r != DF_EMPTY && (k_r >> 7) != rowid,
+             odd_st = k_st != DF_EMPTY && (k_st >> 7) != rowid;
         while (__any(odd_w || odd_r || odd_st)) {
             h_w = odd_w ? (h_w + 1) & (WT - 1) : h_w;
-            h_r = odd_r ? (h_r + 1) & (WT - 1) : h_r;
-            h_st = odd_st ? (h_st + 1) & (WT - 1) : h_st;
-            const int o2 = atomicCAS(&key_w[odd_w ? h_w : WT], odd_w ? -1 : -2, rowid);
-            const int r2 = key_r[odd_r ? h_r : WT];
-            const int s2 = key_st[odd_st ? h_st : WT];
-            const M128 mr2 = lds_mask_load(mask_r[h_r]);
-            const M128 ms2 = lds_mask_load(mask_st[h_st]);
-            if (odd_r) m_r = mr2;
-            if (odd_st) m_st = ms2;
+            h_r = (h_r + 1) & (WT - 1);
+            h_st = (h_st + 1) & (WT - 1);
+            const uint32_t o2 = atomicCAS(&key_w[odd_w ? h_w : WT], odd_w ? DF_EMPTY : DF_EMPTY - 1u, mine);
+            const uint32_t r2 = key_r[odd_r ? h_r : WT];
+            const uint32_t s2 = key_st[odd_st ? h_st : WT];
             o_w = odd_w ? o2 : o_w; k_r = odd_r ? r2 : k_r; k_st = odd_st ? s2 : k_st;
-            odd_w = o_w != -1 && o_w != rowid; odd_r = k_r != -1 && k_r != rowid; odd_st = k_st != -1 && k_st != rowid;
+            odd_w = o_w != DF_EMPTY && (o_w >> 7) != rowid; odd_r = k_r != DF_EMPTY && (k_r >> 7) != rowid;
+            odd_st = k_st != DF_EMPTY && (k_st >> 7) != rowid;
         }
-        atomicOr(&lds.wmask[(k + 1) & 3][h_w][ii >> 5], 1u << (ii & 31));
-        Wn = k_r == rowid ? m_r : m128_zero();
-        Wst = k_st == rowid ? m_st : m128_zero();
+        const int own_w = o_w == DF_EMPTY ? ii : (int)(o_w & 127u);
+        atomicOr(&lds.wmask[(k + 1) & 3][own_w][ii >> 5], 1u << (ii & 31));
+        const bool found_r = k_r != DF_EMPTY, found_st = k_st != DF_EMPTY;
+        Wn = m128_zero();
+        Wst = m128_zero();
+        if (__any(found_r || found_st)) {
+            const M128 mr = lds_mask_load(lds.wmask[k & 3][found_r ? (int)(k_r & 127u) : DF_CAP]);
+            const M128 ms = lds_mask_load(lds.wmask[(k + 3) & 3][found_st ? (int)(k_st & 127u) : DF_CAP]);
+            if (found_r) Wn = mr;
+            if (found_st) Wst = ms;
+        }
         w_prev = w_cur; w_cur = w_next; w_next = h_w;
+        own_prev = own_cur; own_cur = own_next; own_next = own_w;
     };
 
     RowV<T, NV> row;  // Q[p.n]: gathered before the barrier in front of the step it serves
@@ -262,13 +294,15 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
         if (active) {
             const M valid0 = valid_mask_lane<Env, NV, MASKED>(ev, i, p.n);
             advance(row, valid0, 0, philox_of(0), c.thr[0], row_nan_lane<NV>(masked_row<MASKED>(row, valid0)));
-            int h = (int)(mix32((uint32_t)p.s) & (WT - 1));
-            int old = atomicCAS(&lds.key[0][h], -1, p.s);
-            while (old != -1 && old != p.s) {
+            const uint32_t rowid = (uint32_t)p.s, mine = (rowid << 7) | (uint32_t)ii;
+            int h = (int)(mix32(rowid) & (WT - 1));
+            uint32_t old = atomicCAS(&lds.key[0][h], DF_EMPTY, mine);
+            while (old != DF_EMPTY && (old >> 7) != rowid) {
                 h = (h + 1) & (WT - 1);
-                old = atomicCAS(&lds.key[0][h], -1, p.s);
+                old = atomicCAS(&lds.key[0][h], DF_EMPTY, mine);
             }
-            atomicOr(&lds.wmask[0][h][ii >> 5], 1u << (ii & 31));
+            own_next = old == DF_EMPTY ? ii : (int)(old & 127u);
+            atomicOr(&lds.wmask[0][own_next][ii >> 5], 1u << (ii & 31));
             w_next = h;
         }
         if (helper) produce(1);
@@ -285,114 +319,154 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     bool timed_out = false;
     for (long long t = 0; t < steps; ++t) {
-        if (lds.abort_) break;  // (set before the barrier every wavefront has just left: a uniform decision)
         const bool last = t + 1 == steps;
         const bool dl_ok = t < dl_steps;
-        // (schedule values one step ahead, as vector loads through a laundered zero offset: see k_rollout_lane)
-        const double lr_next = ((const double*)(uintptr_t)c.lr)[(last ? t : t + 1) + vzero];
-        const unsigned long long thr_next = ((const unsigned long long*)(uintptr_t)c.thr)[(t + 2 < steps ? t + 2 : steps - 1) + vzero];
+        QL_STAMP(7);
         const U4 x = draws(t + 1);
         if (helper && !last) produce(t + 2);
-        const uint32_t stamp = (uint32_t)t + 1u, stamp_prev = (uint32_t)t;
+        const uint32_t stamp = ((uint32_t)t + 1u) & 0xFFFFFFu, stamp_prev = (uint32_t)t & 0xFFFFFFu;  // (24 bits: a launch is shorter)
         const int par = (int)(t & 1);
         const M valid = valid_mask_lane<Env, NV, MASKED>(ev, ii, p.n);
-        // the row gather (issued before the barrier) has landed
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-        // ---- writers of my row in the step before: their final values bring the gathered row up to date (the
-        // gather ran beside their stores).  They all published before the barrier.
-        if (active && m128_any(Wst)) {
-            M128 w = Wst;
-            while (m128_any(w)) {  // ascending agent index: the highest writer of a column wins
-                const int j = m128_pop_lowest(w);
-                T v;
-                (void)df_pub_read(&lds.pub[par ^ 1][j], stamp_prev, &v);
-                row_set_lane<T, NV>(row, (int)lds.pub_a[(t + 3) & 3][j], v);
-            }
-        }
-        // ---- update of transition t --------------------------------------------------------------------------
-        // lower-indexed writers of the row I write / of the row my maximum is taken over (the reference's order)
+        // the row gather (issued before the barrier) has landed; the table stores issued behind it may still be in flight
+        if constexpr (LEAN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        // Schedule values one step ahead, as vector loads through a laundered zero offset (see k_rollout_lane) -- issued
+        // BEHIND the wait above: in front of it their round trip (a cache miss every eighth step) would sit on the
+        // critical path of every step; here they are simply in flight until the end of the step.
+        const double lr_next = ((const double*)(uintptr_t)c.lr)[(last ? t : t + 1) + vzero];
+        const unsigned long long thr_next = ((const unsigned long long*)(uintptr_t)c.thr)[(t + 2 < steps ? t + 2 : steps - 1) + vzero];
+        // Does any agent of this wavefront share a row with another one?  (The common answer is no: everything
+        // about masks stays out of that path.)
+        const bool company = active && (m128_any(m128_andnot(Ws, my_bit)) || m128_any(Wn) || m128_any(Wst));
+        const bool any_company = __any(company);
         const bool self_loop = p.n == p.s;
-        const M128 S_low = m128_and(Ws, below);
-        const M128 N_low = p.term ? m128_zero() : (self_loop ? S_low : m128_and(Wn, below));
-        const bool dep_u = active && (m128_any(S_low) || m128_any(N_low));
         const float r_t = p.r;
         const bool term_t = p.term;
         const int64_t cell = (int64_t)p.s * (4 * NV) + p.a;
         T q1 = 0, u = 0;
         bool row_nan = false;
-        if (!__any(dep_u)) {
-            // nobody in this wavefront depends on another agent: the quiet path
+        bool dep_u = false;
+        bool is_last = active;  // I am the last writer of my cell in this step: my value goes to the table
+        QL_STAMP(0);
+        if (!any_company) {
+            // ---- quiet: update of transition t from the row as gathered, the value carried from the selection ------
             row_nan = row_nan_lane<NV>(masked_row<MASKED>(row, valid));
             if (active) {
                 T m = row_max_lane(masked_row<MASKED>(row, valid));
                 if (row_nan) m = quiet_nan<T>();
                 q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
-                df_pub_write(&lds.pub[par][ii], stamp, q1);
+                df_pub_write(&lds.pub[par][ii], stamp, q1, p.a);
             }
         } else {
-            // Dataflow rounds.  What each dependent agent needs first: which lower writers of its row write ITS cell
-            // (their latest value is what it updates) -- the columns were published with the selection.
-            M128 sc_low = m128_zero();  // lower writers of my cell
-            int hsc = -1;               // ... the highest of them
-            if (dep_u) {
-                M128 w = S_low;
-                while (m128_any(w)) {
+            DfPub<T>* const pub_now = lds.pub[par];
+            const unsigned char* const cols_now = lds.pub_a[t & 3];
+            // ---- writers of my row in the step before: their final values bring the gathered row up to date (the
+            // gather ran beside their stores).  They all published before the barrier.
+            if (__any(active && m128_any(Wst))) {
+                M128 w = active ? Wst : m128_zero();
+                while (m128_any(w)) {  // ascending agent index: the highest writer of a column wins
                     const int j = m128_pop_lowest(w);
-                    if ((int)lds.pub_a[t & 3][j] == p.a) { sc_low = m128_or(sc_low, m128_bit(j)); hsc = j; }
+                    T v;
+                    int col;
+                    (void)df_pub_read(lds.pub[par ^ 1], lds.pub_a[(t + 3) & 3], j, stamp_prev, &v, &col);
+                    row_set_lane<T, NV>(row, col, v);
                 }
             }
-            bool todo = active;
-            int spin = 0;
-            for (int round = 0; __any(todo) && !timed_out; ++round) {
-                if (todo) {
-                    bool ready = true;
-                    T q0 = p.pred;
-                    RowV<T, NV> rowm = row;  // the row my maximum is taken over
-                    int reps = 1;
-                    if (dep_u) {
-                        if (Env::kSameOutcome && !m128_any(N_low)) {
-                            // nobody below me writes the row I read: every lower writer of my cell has my reward, my
-                            // maximum and my termination flag (same state, same action, an environment whose outcome
-                            // is a function of the two) -- the chain is mine to compute
-                            reps = m128_popc(sc_low) + 1;
-                        } else {
-                            if (hsc >= 0) ready = df_pub_read(&lds.pub[par][hsc], stamp, &q0);
+            // ---- update of transition t: lower-indexed writers of the row I write / of the row my maximum is taken
+            // over (the reference's order)
+            const M128 S_low = m128_and(Ws, below);
+            const M128 N_low = p.term ? m128_zero() : (self_loop ? S_low : m128_and(Wn, below));
+            dep_u = active && (m128_any(S_low) || m128_any(N_low));
+            if (!__any(dep_u)) {
+                // nobody here waits for a value: the plain update (the company is higher-indexed, or only matters for
+                // the selection)
+                if (active) {
+                    T m = row_max_lane(masked_row<MASKED>(row, valid));
+                    if (row_nan_lane<NV>(masked_row<MASKED>(row, valid))) m = quiet_nan<T>();
+                    q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
+                    df_pub_write(&pub_now[ii], stamp, q1, p.a);
+                }
+            } else {
+                // Which lower writers of my row write MY cell (the latest of their values is what I update) -- the
+                // columns were published with the selection.
+                int n_sc = 0;   // lower writers of my cell
+                int hsc = -1;   // ... the highest of them
+                if (dep_u) {
+                    M128 w = S_low;
+                    while (m128_any(w)) {
+                        const int j = m128_pop_lowest(w);
+                        if ((int)cols_now[j] == p.a) { ++n_sc; hsc = j; }
+                    }
+                }
+                // nobody below me writes the row I read: every lower writer of my cell has my reward, my maximum and my
+                // termination flag (same state, same action, an environment whose outcome is a function of the two) --
+                // the chain is mine to compute, nothing to wait for
+                const bool local_chain = Env::kSameOutcome && !m128_any(N_low);
+                const bool waits = dep_u && !local_chain;
+                bool todo = active;
+                int spin = 0;
+                for (int round = 0; __any(todo) && !timed_out; ++round) {
+                    if (todo) {
+                        bool ready = true;
+                        T q0 = p.pred;
+                        // values of the lower writers of the row my maximum is taken over: the first two stay in
+                        // registers (nearly always all of them)
+                        T v0 = 0, v1 = 0;
+                        int c0 = 0, c1 = 0, cnt = 0;
+                        if (waits) {
+                            int col;
+                            if (hsc >= 0) ready = df_pub_read(pub_now, cols_now, hsc, stamp, &q0, &col);
                             M128 w = N_low;
                             while (m128_any(w)) {
                                 const int j = m128_pop_lowest(w);
                                 T v;
-                                ready &= df_pub_read(&lds.pub[par][j], stamp, &v);
-                                row_set_lane<T, NV>(rowm, (int)lds.pub_a[t & 3][j], v);
+                                ready &= df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
+                                if (cnt == 0) { v0 = v; c0 = col; }
+                                if (cnt == 1) { v1 = v; c1 = col; }
+                                ++cnt;
                             }
                         }
+                        if (ready) {
+                            // (patched in place: the selection below brings the row to its final state anyway, with the
+                            // writers' values in the same ascending order)
+                            if (cnt >= 1) row_set_lane<T, NV>(row, c0, v0);
+                            if (cnt >= 2) row_set_lane<T, NV>(row, c1, v1);
+                            if (cnt > 2) {
+                                M128 w = N_low;
+                                while (m128_any(w)) {
+                                    const int j = m128_pop_lowest(w);
+                                    T v;
+                                    int col;
+                                    (void)df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
+                                    row_set_lane<T, NV>(row, col, v);
+                                }
+                            }
+                            T m = row_max_lane(masked_row<MASKED>(row, valid));
+                            if (row_nan_lane<NV>(masked_row<MASKED>(row, valid))) m = quiet_nan<T>();
+                            const int reps = (dep_u && local_chain) ? n_sc + 1 : 1;
+                            T q = q0;
+                            for (int k = 0; k < reps; ++k) q = Td<T>::apply(q, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
+                            q1 = q;
+                            df_pub_write(&pub_now[ii], stamp, q1, p.a);
+                            todo = false;
+                        }
                     }
-                    if (ready) {
-                        const bool nan0 = row_nan_lane<NV>(masked_row<MASKED>(rowm, valid));
-                        T m = row_max_lane(masked_row<MASKED>(rowm, valid));
-                        if (nan0) m = quiet_nan<T>();
-                        T q = q0;
-                        for (int k = 0; k < reps; ++k) q = Td<T>::apply(q, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
-                        q1 = q;
-                        df_pub_write(&lds.pub[par][ii], stamp, q1);
-                        todo = false;
-                    }
+                    if (round) ++extra_rounds;
+                    if (++spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }  // never expected: every wave leaves, error reported
                 }
-                if (round) ++extra_rounds;
-                if (++spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }  // never expected: every wave leaves, error reported
+                dep_total += dep_u ? 1ull : 0ull;
             }
-            dep_total += dep_u ? 1ull : 0ull;
-        }
-        if (active) {
             // the table receives the LAST value of a written cell: by the highest writer of the cell
-            M128 hi = m128_andnot(m128_andnot(Ws, below), my_bit);  // higher writers of my row
-            bool is_last = true;
-            while (m128_any(hi)) {
-                const int j = m128_pop_lowest(hi);
-                is_last &= (int)lds.pub_a[t & 3][j] != p.a;
+            M128 hi = active ? m128_andnot(m128_andnot(Ws, below), my_bit) : m128_zero();  // higher writers of my row
+            if (__any(m128_any(hi))) {
+                while (m128_any(hi)) {
+                    const int j = m128_pop_lowest(hi);
+                    is_last &= (int)cols_now[j] != p.a;
+                }
             }
-            if (is_last) c.q[cell] = q1;
-            if (dl_ok) *dl = DeltaEntry{(uint32_t)cell, (float)u};
         }
+        const float u_t = (float)u;
+        QL_STAMP(2);
         // base_runtime.py:212,218-221 for transition t (staged episode log: see k_rollout_lane)
         unsigned ep_raw = 0;
         unsigned long long enders = 0;
@@ -407,49 +481,72 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                 acc = 0.0f;
             }
         }
+        QL_STAMP(4);
         // ---- selection of transition t+1 from row p.n after EVERY update of step t -----------------------------
         if (!last) {
-            // all writers of that row (any index); on a self-loop the other writers of row p.s, and my own value
-            const M128 F = self_loop ? Ws : Wn;
-            const bool dep_s = active && m128_any(m128_andnot(F, my_bit));
-            const bool any_dep_s = __any(dep_s);
-            if (any_dep_s) {
-                // wait until every writer this wavefront's selections depend on has published (updates never wait
-                // for selections, so this cannot deadlock), then patch
-                for (int spin = 0; !timed_out; ++spin) {
-                    bool ready = true;
-                    if (dep_s) {
-                        M128 w = m128_andnot(F, my_bit);
-                        while (m128_any(w)) {
-                            const int j = m128_pop_lowest(w);
-                            T v;
-                            ready &= df_pub_read(&lds.pub[par][j], stamp, &v);
-                        }
-                    }
-                    if (!__any(!ready)) break;
-                    if (spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }
-                    __builtin_amdgcn_s_sleep(1);
+            if (!any_company) {
+                // (the flag of the update's row serves: an own write into the row adds a NaN exactly when the new value
+                // is one and cannot remove one -- see k_rollout_lane)
+                if (self_loop) {
+                    row_set_lane<T, NV>(row, p.a, q1);
+                    row_nan |= q1 != q1;
                 }
-                if (dep_s && !timed_out) {
-                    M128 w = F;  // ascending, my own write included at its place (self-loop)
+            } else {
+                // all writers of that row (any index); on a self-loop the other writers of row p.s, and my own value
+                DfPub<T>* const pub_now = lds.pub[par];
+                const unsigned char* const cols_now = lds.pub_a[t & 3];
+                const M128 others = m128_andnot(self_loop ? Ws : Wn, my_bit);
+                const bool dep_s = active && m128_any(others);
+                // the first two writers' values stay in registers (nearly always all of them)
+                T v0 = 0, v1 = 0;
+                int c0 = 0, c1 = 0, j0 = 0, j1 = 0, cnt = 0;
+                if (__any(dep_s)) {
+                    // wait until every writer this wavefront's selections depend on has published (updates never wait
+                    // for selections, so this cannot deadlock)
+                    for (int spin = 0; !timed_out; ++spin) {
+                        bool ready = true;
+                        cnt = 0;
+                        if (dep_s) {
+                            M128 w = others;
+                            while (m128_any(w)) {
+                                const int j = m128_pop_lowest(w);
+                                T v;
+                                int col;
+                                ready &= df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
+                                if (cnt == 0) { v0 = v; c0 = col; j0 = j; }
+                                if (cnt == 1) { v1 = v; c1 = col; j1 = j; }
+                                ++cnt;
+                            }
+                        }
+                        if (!__any(!ready)) break;
+                        if (spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                // patches in ascending agent index (the highest writer of a column wins), my own write at its place
+                if (dep_s && cnt <= 2) {
+                    if (cnt >= 1 && j0 < ii) row_set_lane<T, NV>(row, c0, v0);
+                    if (cnt >= 2 && j1 < ii) row_set_lane<T, NV>(row, c1, v1);
+                    if (self_loop) row_set_lane<T, NV>(row, p.a, q1);
+                    if (cnt >= 1 && j0 > ii) row_set_lane<T, NV>(row, c0, v0);
+                    if (cnt >= 2 && j1 > ii) row_set_lane<T, NV>(row, c1, v1);
+                } else if (dep_s) {
+                    M128 w = self_loop ? Ws : Wn;
                     while (m128_any(w)) {
                         const int j = m128_pop_lowest(w);
                         T v;
-                        (void)df_pub_read(&lds.pub[par][j], stamp, &v);
-                        row_set_lane<T, NV>(row, (int)lds.pub_a[t & 3][j], v);
+                        int col;
+                        (void)df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
+                        row_set_lane<T, NV>(row, col, v);
                     }
+                } else if (active && self_loop) {
+                    row_set_lane<T, NV>(row, p.a, q1);  // own write lands in the row I hold
                 }
-            }
-            if (active && self_loop && !dep_s) row_set_lane<T, NV>(row, p.a, q1);  // own write lands in the row I hold
-            if (any_dep_s || __any(dep_u)) {
                 row_nan = row_nan_lane<NV>(masked_row<MASKED>(row, valid));
-            } else if (self_loop) {
-                // (quiet: the flag of the update's row serves; an own write into the row adds a NaN exactly when the
-                // new value is one and cannot remove one -- see k_rollout_lane)
-                row_nan |= q1 != q1;
             }
             if (active) advance(row, valid, t + 1, x, thr_t1, row_nan);
         }
+        QL_STAMP(5);
         if (enders) {  // entry k of this flush window lands at log position ep_base + k
             const unsigned base = __builtin_amdgcn_readlane(ep_raw, __ffsll((long long)enders) - 1);
             if ((enders >> (threadIdx.x & 63)) & 1) {
@@ -470,10 +567,12 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
             }
         }
         // ---- bulk flush of the staged episode log (uniform, data-independent decision) ----------
+        bool leave = false;
         if (--flush_in == 0 || last) {
             flush_in = flush_every;
             __syncthreads();
             const unsigned staged = lds.ep_n;
+            leave = lds.abort_ != 0u;  // a wait ran into its bound: every wavefront reads the same here and leaves
             const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
             unsigned long long* const out_key = cc.ep_key;
             float* const out_ret = cc.ep_ret;
@@ -486,19 +585,46 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
             __syncthreads();
             if (tid == 0) lds.ep_n = 0u;
         }
-        if (last) break;
+        QL_STAMP(6);
+        if (last || leave) {  // no further gather: the stores of this step go out now
+            if (is_last) c.q[cell] = q1;
+            if (LEAN == 2 && active && dl_ok) *dl = DeltaEntry{(uint32_t)cell, u_t};
+            break;
+        }
         // ---- transition t+1 is pending in p: gather its row; under the gather the bookkeeping; retire my entry of
-        // the set of step t-1 (key and writers; sharers of an entry write the same) ---------------------------------
-        lds.key[(t + 3) & 3][w_prev] = -1;
-        *reinterpret_cast<uint4*>(lds.wmask[(t + 3) & 3][w_prev]) = make_uint4(0u, 0u, 0u, 0u);
-        asm volatile("" ::: "memory");  // the gather stays behind every store of this step (vmcnt counts in order)
-        if (!helper) load_row_lane<NV>(row, c.q, p.n);
+        // the set of step t-1 (every writer of a row frees its slot, the owner clears the writers' mask) ---------------
+        lds.key[(t + 3) & 3][w_prev] = DF_EMPTY;
+        *reinterpret_cast<uint4*>(lds.wmask[(t + 3) & 3][own_prev == ii ? ii : DF_CAP]) = make_uint4(0u, 0u, 0u, 0u);
+        // The table store of step t is issued BEHIND the gather of step t+1 (nobody reads the table for a value of this
+        // step: see the barrier below): the vector-memory counter counts in order, so a store in front of the gather
+        // would make the wait for the gathered row at the top of the next step a wait for the store's acknowledgement
+        // (~1 us) as well.  Every lane stores (the ones that must not, into a per-agent dump word) so that the wait can
+        // name the number of stores behind the gather.
+        asm volatile("" ::: "memory");
+        if (!helper) {
+            load_row_lane<NV>(row, c.q, p.n);
+            asm volatile("" ::: "memory");
+            *(is_last ? c.q + cell : c.pred + ii) = q1;
+            if constexpr (LEAN == 2) {
+                DeltaEntry* const rec = (active && dl_ok) ? dl : reinterpret_cast<DeltaEntry*>(c.pred) + ii;
+                *rec = DeltaEntry{(uint32_t)cell, u_t};
+            }
+        }
         asm volatile("" ::: "memory");
         if (active) bookkeeping(t + 1, false);
-        step_barrier<NLOAD>();  // table writes of step t are complete; the sets of steps t+1, t+2 are in
+        QL_STAMP(1);
+        // Step barrier: LDS traffic complete (the sets of steps t+1, t+2 are in, everything of step t is published), all
+        // wavefronts have arrived.  NOT a wait for this step's table stores: nobody reads the table for a value written
+        // in this step (the row gathered above is brought up to date from LDS, Wst), and the gathers of later steps are
+        // issued behind this barrier by wavefronts of the same CU, whose vector-memory requests reach the cache in
+        // issue order behind the stores.  Their acknowledgement (~1 us) would otherwise bound the step from below.
+        barrier_lds();
         lr_t = lr_next; thr_t1 = thr_next;
         if (c.dlog) dl += c.N;
     }
+#ifdef QE_STAMPS
+    if (tid == 0 && c.vinc) for (int k = 0; k < 8; ++k) c.vinc[k] = (double)stamp_sum[k];
+#endif
     const Ctx<T>& cc = *reinterpret_cast<const Ctx<T>*>(lds.cold);
     if (active) {
         cc.n[i] = p.n; cc.aux[i] = p.aux; cc.acc[i] = acc;

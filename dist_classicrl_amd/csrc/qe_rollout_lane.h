@@ -94,17 +94,19 @@ __device__ __forceinline__ T row_max_lane(const RowV<T, NV>& rowm) {
 // Whether a (masked) row holds a NaN: np.max returns it (q_learning_optimal.py:548, :757-761), the maximum above
 // does not.  Sum of squares: every term is >= 0 or NaN, so no inf - inf can arise and the sum is NaN exactly when
 // some column is (x * x and the adds may overflow to +inf, never to NaN).  Two columns per instruction
-// (v_pk_mul_f32 / v_pk_add_f32 on float2) on a float32 row.  (Contraction is off: mul and add stay separate, which
-// changes nothing here -- only NaN-ness is read.)
+// (v_pk_fma_f32 on float2) on a float32 row; only NaN-ness is read, so fusing changes nothing.
 template <int NV>
 __device__ __forceinline__ bool row_nan_lane(const RowV<float, NV>& rowm) {
     typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 acc = {0.0f, 0.0f};
+    // (fused multiply-adds, two accumulators: v_pk_fma_f32 has a long dependent-issue distance)
+    f2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};
 #pragma unroll
-    for (int j = 0; j < 4 * NV; j += 2) {
-        const f2 x = {rowm.v[j], rowm.v[j + 1]};
-        acc += x * x;
+    for (int j = 0; j < 4 * NV; j += 4) {
+        const f2 x = {rowm.v[j], rowm.v[j + 1]}, y = {rowm.v[j + 2], rowm.v[j + 3]};
+        acc0 = __builtin_elementwise_fma(x, x, acc0);
+        acc1 = __builtin_elementwise_fma(y, y, acc1);
     }
+    const f2 acc = acc0 + acc1;
     const float s = acc.x + acc.y;
     return s != s;
 }
@@ -444,11 +446,6 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
     for (long long t = 0; t < steps; ++t) {
         const bool last = t + 1 == steps;
         const bool dl_ok = t < dl_steps;
-        // (vector loads through a laundered zero offset: as scalar loads the compiler waits for each of them
-        // on the spot -- two scalar-memory round trips in front of every step; a vector load is simply in
-        // flight until the values are used, at the end of the step)
-        const double lr_next = ((const double*)(uintptr_t)c.lr)[(last ? t : t + 1) + vzero];
-        const unsigned long long thr_next = ((const unsigned long long*)(uintptr_t)c.thr)[(t + 2 < steps ? t + 2 : steps - 1) + vzero];
         QL_STAMP(7);
         const bool busy = lds.busy[t & 3] != 0u;
         const U4 x = draws(t + 1);
@@ -521,6 +518,12 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         // leaves the loads "pending" in its analysis, and it drains vector memory -- this step's table
         // store included -- in front of the NEXT gather.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        // Schedule values of the next step (vector loads through a laundered zero offset: as scalar loads the compiler
+        // waits for each of them on the spot -- two scalar-memory round trips in front of every step; a vector load is
+        // simply in flight until the values are used, at the end of the step).  Issued BEHIND the wait above: in front
+        // of it that wait would be a wait for their round trip as well (a cache miss every eighth step).
+        const double lr_next = ((const double*)(uintptr_t)c.lr)[(last ? t : t + 1) + vzero];
+        const unsigned long long thr_next = ((const unsigned long long*)(uintptr_t)c.thr)[(t + 2 < steps ? t + 2 : steps - 1) + vzero];
         const float r_t = p.r;
         const bool term_t = p.term;
         // ---- update of transition t for agents that may go now ----------------------------------

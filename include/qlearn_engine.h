@@ -118,8 +118,9 @@ enum qe_option { QE_OPT_ROLLOUT_PATH = 0, QE_OPT_USE_GRAPH = 1 /* 1 (default): r
                                           episode log) into page-locked host memory itself and qe_rollout_end spins on a sequence
                                           word there; 0: stream synchronisation + copies */,
                  QE_OPT_LANE_ORDERED_PATH = 6 /* persistent path, plain training rollouts of up to 128 agents: 0 (default) = automatic,
-                                                 1 = the dataflow kernel (no general ordered path: sharers of a row hand their
-                                                 values on in LDS), 2 = the build with the general ordered path */,
+                                                 1 = the dataflow kernel (sharers of a row hand their values on in LDS), 2 = the
+                                                 build with the general ordered path (deep chains of sharers), 3 = the sparse
+                                                 build (rows rarely shared; full wavefronts only, else 1) */,
                  QE_OPT_TURN_FORWARD = 7 /* turnstile path, fp32 tables: 1 (default) = a row's progress word carries the value its last
                                             writer stored, successors whose view of the row can differ in that one column only take it
                                             from their poll; 0 = they always re-read the table (measurement switch) */ };

@@ -127,7 +127,7 @@ def test_tables_that_hold_nan_follow_the_reference(spec, chunks, dt, mode, sched
     _compare(got, want)
 
 
-@pytest.mark.parametrize("ordered_path", [1, 2])
+@pytest.mark.parametrize("ordered_path", [1, 2, 3])
 @pytest.mark.parametrize(("spec", "chunks", "sched", "cells", "tseed"), [
     (("hash", 128, 2000, 16, False), [20, 20, 20, 20], "const", 1, 4),   # IndexError in the 3rd call
     (("hash", 128, 2000, 16, False), [64, 64], "explore", 1600, 3),
