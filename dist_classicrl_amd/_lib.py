@@ -130,6 +130,8 @@ PROTOTYPES = {
     "qe_delta_apply_dev": (C.c_int, [_P, _P, C.c_int64]),
     "qe_delta_apply_skip_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64]),
     "qe_delta_apply_sorted_dev": (C.c_int, [_P, _P, C.c_int64]),
+    "qe_delta_apply_gathered_dev": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "qe_debug_occupy_cus": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "qe_replay_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int64]),
     "qe_replay_destroy": (C.c_int, [_P]),
     "qe_replay_push": (C.c_int, [_P, _I64P, _I64P, _F64P, _I64P, _U8P, C.c_int64]),

@@ -3,6 +3,7 @@
 // (The rollout kernels are instantiated in qe_inst_lane.hip / qe_inst_step.hip, one object per table dtype and
 // environment; this file holds everything that is not templated on them.)
 #include "qe_host.h"
+#include "qe_delta_sort.h"
 
 namespace {
 thread_local std::string g_err;
@@ -236,8 +237,15 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         return qe_fail(QE_ERR_UNSUPPORTED, "persistent rollout needs num_agents <= 512 and action_size <= 64 (have %lld agents, %d actions)",
                     (long long)env->N, (int)e->A);
     // turnstile path: one launch per step, all workgroups resident, rows handed from agent to agent
-    const bool turn = learn && !persistent && mode == QE_LEARN_ITER && turn_fits(e, env->N) &&
-                      (e->opt_path == 4 || (e->opt_path == 0 && TURN_AUTO));
+    bool turn = false;
+    if (learn && !persistent && mode == QE_LEARN_ITER && (e->opt_path == 4 || (e->opt_path == 0 && TURN_AUTO))) {
+        int& per_cu = e->turn_blocks_per_cu[env->p.kind & 3];
+        if (per_cu == 0) {
+            per_cu = turn_occupancy<T, Env>(e);
+            if (per_cu <= 0) per_cu = -1;  // (asked once; without an answer the path is not taken)
+        }
+        turn = turn_fits(e, env->N, per_cu);
+    }
     if (turn) {
         const size_t words = (size_t)env->N * 4;
         HIP_TRY(env->turn_next.ensure(words));
@@ -647,10 +655,12 @@ int qe_destroy(qe_engine* e) {
     e->plan_thr.release(); e->plan_lr.release(); e->h_plan_thr.release(); e->h_plan_lr.release();
     e->h_stage.release(); e->warm_scratch.release();
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->debug_stream) { (void)hipStreamSynchronize(e->debug_stream); (void)hipStreamDestroy(e->debug_stream); }
     e->thr.release(); e->lr.release(); e->b_s.release(); e->b_a.release(); e->b_n.release();
     e->b_out.release(); e->b_list.release(); e->b_r.release(); e->b_acc.release(); e->b_term.release();
     e->b_pred.release(); e->b_aux.release(); e->b_mask.release(); e->b_bitmap.release();
     e->b_vals.release(); e->b_vinc.release(); e->ep_key.release(); e->ep_ret.release(); e->trace.release();
+    e->ds_a.release(); e->ds_b.release(); e->ds_hist.release();
     if (e->stream && e->own_stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return QE_OK;
@@ -1261,6 +1271,69 @@ int qe_delta_apply_sorted_dev(qe_engine* e, const void* dev_entries, int64_t cou
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(k_delta_apply_sorted<float>, dim3(grid_for(count, 256)), dim3(256), 0, e->stream, (float*)e->q,
                        (const DeltaEntry*)dev_entries, count);
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+int qe_delta_apply_gathered_dev(qe_engine* e, const void* gathered_dev, int64_t capacity, int64_t count, int32_t world,
+                                int32_t rank) {
+    if (!e || !gathered_dev || capacity <= 0 || count < 0 || count > capacity || world < 1 || rank < 0 || rank >= world)
+        return qe_fail(QE_ERR_INVALID, "bad argument");
+    const int64_t n = (int64_t)(world - 1) * count;
+    if (n <= 0) return QE_OK;
+    if (n >= ((int64_t)1 << 32)) return qe_fail(QE_ERR_UNSUPPORTED, "more than 2^32 - 1 remote records in one exchange");
+    if (e->dtype != QE_F32) return qe_fail(QE_ERR_UNSUPPORTED, "delta apply needs a float32 table");
+    HIP_TRY(hipSetDevice(e->device));
+    const int n_tiles = (int)((n + DSORT_TILE - 1) / DSORT_TILE);
+    HIP_TRY(e->ds_a.ensure((size_t)n));
+    HIP_TRY(e->ds_b.ensure((size_t)n));
+    HIP_TRY(e->ds_hist.ensure((size_t)DSORT_BINS * n_tiles + 1));
+    unsigned* const flag = e->ds_hist.p + (size_t)DSORT_BINS * n_tiles;
+    // digits of the cell index that can differ
+    const uint64_t cells = (uint64_t)e->S * (uint64_t)e->ld;
+    int bits = 1;
+    while (bits < 32 && (cells - 1) >> bits) ++bits;
+    const int passes = (bits + 7) / 8;
+    const DeltaEntry* in = (const DeltaEntry*)gathered_dev;
+    DeltaEntry* bufs[2] = {e->ds_a.p, e->ds_b.p};
+    for (int p = 0; p < passes; ++p) {
+        DeltaEntry* const out = bufs[p & 1];
+        const int first = p == 0 ? 1 : 0;
+        hipLaunchKernelGGL(k_dsort_count, dim3(n_tiles), dim3(64), 0, e->stream, in, (long long)n, 8 * p, first, (long long)count,
+                           (long long)capacity, (int)rank, e->ds_hist.p, n_tiles);
+        hipLaunchKernelGGL(k_dsort_scan, dim3(1), dim3(1024), 0, e->stream, e->ds_hist.p, (long long)DSORT_BINS * n_tiles, n_tiles,
+                           (long long)n, flag);
+        hipLaunchKernelGGL(k_dsort_scatter, dim3(n_tiles), dim3(64), 0, e->stream, in, out, (long long)n, 8 * p, first,
+                           (long long)count, (long long)capacity, (int)rank, (const unsigned*)e->ds_hist.p, n_tiles,
+                           (const unsigned*)flag);
+        in = out;
+    }
+    hipLaunchKernelGGL(k_delta_apply_sorted<float>, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, (float*)e->q, in, n);
+    HIP_TRY(hipGetLastError());
+    return QE_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------
+// A kernel of `blocks` workgroups that each keep a whole CU's LDS (so no two share a CU) and spin for `microseconds`
+// of the constant-rate clock (bounded: at most 200 ms), launched on a stream of its own and NOT waited for: tests use
+// it to take part of the chip away while a rollout runs (the situation of a collective beside the next chunk).
+__global__ __launch_bounds__(256) void k_debug_occupy(long long ticks, unsigned* sink) {
+    __shared__ unsigned hog[30000];  // 120 KB of the CU's 160: a second workgroup of this kernel does not fit
+    hog[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    unsigned acc = 0;
+    while (wall_clock64() - t0 < ticks) acc += hog[(threadIdx.x * 7 + acc) % 30000];
+    if (acc == 0xFFFFFFFFu) sink[0] = acc;
+}
+
+int qe_debug_occupy_cus(qe_engine* e, int32_t blocks, int32_t microseconds) {
+    if (!e || blocks <= 0 || microseconds <= 0) return qe_fail(QE_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->debug_stream) HIP_TRY(hipStreamCreateWithFlags(&e->debug_stream, hipStreamNonBlocking));
+    const long long us = std::min<long long>(microseconds, 200000);
+    const long long ticks = (long long)((double)us * e->wall_clock_khz / 1000.0);
+    hipLaunchKernelGGL(k_debug_occupy, dim3((unsigned)blocks), dim3(256), 0, e->debug_stream, ticks, (unsigned*)e->ctrl);
     HIP_TRY(hipGetLastError());
     return QE_OK;
 }

@@ -158,7 +158,8 @@ struct qe_engine {
     int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
     unsigned long long turn_epoch = 1;  // turnstile path: list tag of the next call's step 0 (0 = the touch counters' rest value)
     bool stamps_hold_lists = false;     // the touch-counter array holds turnstile list heads (cleared before counters use it)
-    int turn_blocks_per_cu = 0;         // resident workgroups per CU the turnstile kernels are dispatched for (0: not yet queried)
+    int turn_blocks_per_cu[4] = {0, 0, 0, 0};  // resident workgroups of k_step_turn per CU, by environment kind (0: not yet asked)
+    hipStream_t debug_stream = nullptr;        // qe_debug_occupy_cus
     int opt_graph = 1; // QE_OPT_USE_GRAPH
     int opt_rounds = 0; // QE_OPT_TOKEN_ROUNDS (0 = automatic)
     int auto_rounds = 4; // wide mode: rounds chosen from the previous call's statistics
@@ -195,6 +196,9 @@ struct qe_engine {
     DeltaEntry* dlog = nullptr;
     long long dlog_cap = 0, dlog_count = 0;
     DevBuf<int32_t> trace;
+    // replica exchange: ping-pong buffers and digit counts of the radix sort of the remote records (qe_delta_sort.h)
+    DevBuf<DeltaEntry> ds_a, ds_b;
+    DevBuf<unsigned> ds_hist;
     // schedule plan (qe_schedule_plan): values of a whole training call, consumed by the rollouts
     DevBuf<unsigned long long> plan_thr;
     DevBuf<double> plan_lr;
@@ -280,14 +284,17 @@ Ctx<T> env_ctx(qe_engine* e, qe_env* env) {
 
 inline unsigned grid_for(int64_t threads, int block) { return (unsigned)((threads + block - 1) / block); }
 
-// Turnstile path (qe_step_turn.h): its workgroups wait for each other inside the launch, so all of them
-// must be resident -- FAST_BLOCK threads each, TURN_BLOCKS_PER_CU per CU asked for (the kernels need
-// <= 128 registers: four workgroups of four wavefronts fit a CU) -- and the progress counts are 16 bits.
-constexpr int TURN_BLOCKS_PER_CU = 2;
+// Turnstile path (qe_step_turn.h): its workgroups wait for each other inside the launch, so all of them must be
+// resident -- FAST_BLOCK threads each.  How many fit a CU is asked of the runtime for the very kernel that will be
+// launched (hipOccupancyMaxActiveBlocksPerMultiprocessor, turn_occupancy<T, Env> in qe_inst_step.hip); a quarter of the
+// chip is left out of the count, for kernels that share it with the rollout (the collectives of the replica exchange
+// run beside the next chunk).  The progress counts are 16 bits.
+constexpr int TURN_RESERVE_DIV = 4;   // 1 / TURN_RESERVE_DIV of the CUs is not counted on
 constexpr bool TURN_AUTO = true;  // automatic choice for agent counts above the persistent kernel's
-inline bool turn_fits(const qe_engine* e, int64_t N) {
+inline bool turn_fits(const qe_engine* e, int64_t N, int blocks_per_cu) {
     const int64_t blocks = (N * e->L + FAST_BLOCK - 1) / FAST_BLOCK;
-    return N <= 60000 && blocks <= (int64_t)e->num_cus * TURN_BLOCKS_PER_CU && e->ld <= 256;
+    const int64_t cus = (int64_t)e->num_cus - e->num_cus / TURN_RESERVE_DIV;
+    return N <= 60000 && blocks_per_cu > 0 && blocks <= cus * blocks_per_cu && e->ld <= 256;
 }
 // The touch-counter array doubles as the turnstile path's list heads; the counters' kernels expect zeros.
 inline int stamps_as_counters(qe_engine* e) {
@@ -324,3 +331,6 @@ template <typename T, class Env>
 int launch_stepwise(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int64_t steps, bool turn);
 template <typename T, class Env>
 int launch_eval(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int64_t steps);
+// resident workgroups per CU of the k_step_turn build this engine would launch (occupancy query), 0 on failure
+template <typename T, class Env>
+int turn_occupancy(const qe_engine* e);

@@ -157,6 +157,27 @@ int launch_stepwise(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx
     return QE_OK;
 }
 
+template <typename T, class Env>
+int turn_occupancy(const qe_engine* e) {
+    int nb = 0;
+    hipError_t err = hipErrorInvalidValue;
+    auto ask = [&](auto lc) {
+        constexpr int LC = decltype(lc)::value;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_step_turn<T, Env, LC>, FAST_BLOCK, 0);
+    };
+    if constexpr (std::is_same<Env, HashEnv>::value) {  // (same choice as launch_step_any)
+        switch (e->L) {
+            case 4: ask(std::integral_constant<int, 4>{}); break;
+            case 8: ask(std::integral_constant<int, 8>{}); break;
+            case 16: ask(std::integral_constant<int, 16>{}); break;
+            default: ask(std::integral_constant<int, 0>{}); break;
+        }
+    } else {
+        ask(std::integral_constant<int, 0>{});
+    }
+    return err == hipSuccess ? nb : 0;
+}
+
 // greedy evaluation: no table writes, hence no contention and no ordered path
 template <typename T, class Env>
 int launch_eval(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev, int64_t steps) {
@@ -168,3 +189,4 @@ int launch_eval(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& ev
 
 template int launch_stepwise<QE_INST_T, QE_INST_ENV>(qe_engine*, RolloutSlot&, const Ctx<QE_INST_T>&, const EnvCtx&, int64_t, bool);
 template int launch_eval<QE_INST_T, QE_INST_ENV>(qe_engine*, RolloutSlot&, const Ctx<QE_INST_T>&, const EnvCtx&, int64_t);
+template int turn_occupancy<QE_INST_T, QE_INST_ENV>(const qe_engine*);

@@ -33,7 +33,10 @@ import torch.distributed as dist
 
 class DeltaSync:
     def __init__(self, capacity: int, device, apply_fn, attach_fn=None, group=None, overlap: bool = True,
-                 stream=None, apply_skip_fn=None, apply_sorted_fn=None) -> None:
+                 stream=None, apply_skip_fn=None, apply_sorted_fn=None, apply_gathered_fn=None) -> None:
+        # (gathered buffer, capacity, count, world, rank): the whole deterministic apply step inside the engine --
+        # radix sort of the other ranks' records by cell + one sequential run per cell, no torch compute
+        self.apply_gathered_fn = apply_gathered_fn
         self.stream = stream  # torch.cuda.Stream the engine runs on (None on CPU / current stream)
         self.apply_skip_fn = apply_skip_fn  # (entries, total, skip_begin, skip_end): one-launch form
         # (entries sorted by cell, total): deterministic form -- every cell receives the other ranks'
@@ -78,6 +81,8 @@ class DeltaSync:
         g = self.gathered[buf]
         if self.world == 1:
             pass  # nobody else's records
+        elif self.apply_gathered_fn is not None:
+            self.apply_gathered_fn(g, self.capacity, count, self.world, self.rank)
         elif self.apply_sorted_fn is not None:
             others = torch.cat([g[r, :count] for r in range(self.world) if r != self.rank])
             order = torch.sort(others[:, 0], stable=True).indices  # by cell; ties keep (rank, slot) order
@@ -136,10 +141,12 @@ def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overl
                   deterministic: bool = True) -> DeltaSync:
     """Wire a :class:`DeltaSync` to a HIP engine living on the current CUDA device.
 
-    ``deterministic`` (default): the other ranks' records are sorted by cell (torch, on the engine's
-    stream -- plumbing) and added by ``qe_delta_apply_sorted_dev`` in (rank, slot) order per cell, so a
-    replica is reproducible bit for bit; ``False`` adds them with float atomics in arrival order (one
-    launch, no sort)."""
+    ``deterministic`` (default ``True``): the other ranks' records are stably sorted by cell and added in
+    (rank, slot) order per cell INSIDE the engine (``qe_delta_apply_gathered_dev``: hand-written radix sort +
+    sequential runs, ``csrc/qe_delta_sort.h``), so a replica is reproducible bit for bit; ``"torch-sort"`` does
+    the same with ``torch.cat`` / a stable ``torch.sort`` in front of ``qe_delta_apply_sorted_dev`` (round 2's
+    path, kept to check the two against each other); ``False`` adds the records with float atomics in arrival
+    order (one launch, no sort)."""
     import ctypes as C
 
     from dist_classicrl_amd import _lib
@@ -168,7 +175,12 @@ def attach_engine(algorithm, sync_every: int, num_agents: int, group=None, overl
         # (the sorted copy must outlive the kernel that reads it: keep it until the next exchange)
         apply_sorted_fn.keep = entries
 
+    def apply_gathered_fn(gathered, cap, count, world, rank):
+        _lib.check(lib.qe_delta_apply_gathered_dev(algorithm.handle, C.c_void_p(gathered.data_ptr()), int(cap), int(count),
+                                                   int(world), int(rank)))
+
     sync = DeltaSync(capacity, dev, apply_fn, attach_fn, group, overlap, stream, apply_skip_fn,
-                     apply_sorted_fn if deterministic else None)
+                     apply_sorted_fn if deterministic == "torch-sort" else None,
+                     apply_gathered_fn if deterministic is True else None)
     stream.wait_stream(torch.cuda.current_stream())  # buffer initialisation ran on the current stream
     return sync

@@ -241,6 +241,19 @@ int qe_delta_apply_skip_dev(qe_engine* e, const void* dev_entries, int64_t count
  * cell they are in rank-major, slot-minor order); every cell receives its additions sequentially in that
  * order -- no float atomics, the same result on every run. */
 int qe_delta_apply_sorted_dev(qe_engine* e, const void* dev_entries, int64_t count);
+/* The whole apply step of one exchange: `gathered_dev` is the all-gathered buffer, `world` segments of `capacity`
+ * records of which the first `count` are valid; the records of every rank but `rank` are stably sorted by cell inside
+ * the engine (radix sort, csrc/qe_delta_sort.h) and added per cell in rank-major, slot-minor order.  Same result as
+ * qe_delta_apply_sorted_dev over the concatenated, stably sorted records; nothing but HIP kernels on the engine's stream.
+ * (Stands in for the parameter server's apply loop, q_learning_async_dist.py:359-447.) */
+int qe_delta_apply_gathered_dev(qe_engine* e, const void* gathered_dev, int64_t capacity, int64_t count, int32_t world,
+                                int32_t rank);
+
+/* ---- diagnostics -----------------------------------------------------------------------------------
+ * Occupies `blocks` CUs (one workgroup each, most of a CU's LDS) for `microseconds` (at most 200 000) on a stream of its
+ * own and returns at once: tests take part of the chip away with it while a rollout runs, the situation of a collective
+ * running beside the next chunk of a replica (nothing in the reference to stand in for). */
+int qe_debug_occupy_cus(qe_engine* e, int32_t blocks, int32_t microseconds);
 
 /* ---- experience replay (algorithms/buffers/experience_replay.py:13-120; WIP and unused upstream) --
  * Ring buffer of (state, action, reward, next_state, done) in HBM.  Index SELECTION stays with the
