@@ -1287,8 +1287,9 @@ int qe_delta_apply_gathered_dev(qe_engine* e, const void* gathered_dev, int64_t 
     const int n_tiles = (int)((n + DSORT_TILE - 1) / DSORT_TILE);
     HIP_TRY(e->ds_a.ensure((size_t)n));
     HIP_TRY(e->ds_b.ensure((size_t)n));
-    HIP_TRY(e->ds_hist.ensure((size_t)DSORT_BINS * n_tiles + 1));
-    unsigned* const flag = e->ds_hist.p + (size_t)DSORT_BINS * n_tiles;
+    HIP_TRY(e->ds_hist.ensure((size_t)DSORT_BINS * (n_tiles + 1) + 1));  // counts per (digit, tile) | digit totals | flag
+    unsigned* const totals = e->ds_hist.p + (size_t)DSORT_BINS * n_tiles;
+    unsigned* const flag = totals + DSORT_BINS;
     // digits of the cell index that can differ
     const uint64_t cells = (uint64_t)e->S * (uint64_t)e->ld;
     int bits = 1;
@@ -1301,11 +1302,11 @@ int qe_delta_apply_gathered_dev(qe_engine* e, const void* gathered_dev, int64_t 
         const int first = p == 0 ? 1 : 0;
         hipLaunchKernelGGL(k_dsort_count, dim3(n_tiles), dim3(64), 0, e->stream, in, (long long)n, 8 * p, first, (long long)count,
                            (long long)capacity, (int)rank, e->ds_hist.p, n_tiles);
-        hipLaunchKernelGGL(k_dsort_scan, dim3(1), dim3(1024), 0, e->stream, e->ds_hist.p, (long long)DSORT_BINS * n_tiles, n_tiles,
-                           (long long)n, flag);
+        hipLaunchKernelGGL(k_dsort_scan_rows, dim3(DSORT_BINS), dim3(256), 0, e->stream, e->ds_hist.p, n_tiles, totals);
+        hipLaunchKernelGGL(k_dsort_scan_digits, dim3(1), dim3(256), 0, e->stream, totals, (long long)n, flag);
         hipLaunchKernelGGL(k_dsort_scatter, dim3(n_tiles), dim3(64), 0, e->stream, in, out, (long long)n, 8 * p, first,
-                           (long long)count, (long long)capacity, (int)rank, (const unsigned*)e->ds_hist.p, n_tiles,
-                           (const unsigned*)flag);
+                           (long long)count, (long long)capacity, (int)rank, (const unsigned*)e->ds_hist.p,
+                           (const unsigned*)totals, n_tiles, (const unsigned*)flag);
         in = out;
     }
     hipLaunchKernelGGL(k_delta_apply_sorted<float>, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, (float*)e->q, in, n);
