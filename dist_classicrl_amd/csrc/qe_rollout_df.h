@@ -70,6 +70,14 @@ __device__ __forceinline__ int m128_pop_lowest(M128& a) {
     return in_lo ? b : 64 + b;
 }
 
+// the two lowest members of a mask (-1: none) and the member count
+__device__ __forceinline__ int m128_two_lowest(M128 a, int* j0, int* j1) {
+    const int cnt = m128_popc(a);
+    *j0 = cnt >= 1 ? m128_pop_lowest(a) : -1;
+    *j1 = cnt >= 2 ? m128_pop_lowest(a) : -1;
+    return cnt;
+}
+
 template <typename T>
 struct DfPub {
     T val;
@@ -140,6 +148,28 @@ template <typename T, int NV>
 __device__ __forceinline__ void row_set_lane(RowV<T, NV>& row, int col, T v) {
 #pragma unroll
     for (int j = 0; j < 4 * NV; ++j) row.v[j] = j == col ? v : row.v[j];
+}
+
+// np.max of a (masked) row whose columns c0 / c1 (-1: none) are replaced by v0 / v1 (the later one wins on a tie of
+// columns): the maximum of the untouched columns is computed ONCE (`rest`, `rest_nan`), every poll round only adds
+// the replacements.  `valid` masks the replacements like the row.
+template <typename T, int NV, typename M>
+__device__ __forceinline__ void row_rest_lane(const RowV<T, NV>& rowm, int c0, int c1, T* rest, bool* rest_nan) {
+    RowV<T, NV> r;
+#pragma unroll
+    for (int j = 0; j < 4 * NV; ++j) r.v[j] = (j == c0 || j == c1) ? neg_inf<T>() : rowm.v[j];
+    *rest = row_max_lane(r);
+    *rest_nan = row_nan_lane<NV>(r);  // (-inf squares to +inf: no NaN from the placeholders)
+}
+template <typename T, typename M>
+__device__ __forceinline__ T max_with_patches(T rest, bool rest_nan, M valid, int cnt, int c0, T v0, int c1, T v1) {
+    const bool use0 = cnt >= 1 && ((valid >> c0) & 1) && !(cnt >= 2 && c1 == c0);
+    const bool use1 = cnt >= 2 && ((valid >> c1) & 1);
+    T m = rest;
+    if (use0) m = lane_fmax(m, v0);
+    if (use1) m = lane_fmax(m, v1);
+    const bool nan = rest_nan || (use0 && v0 != v0) || (use1 && v1 != v1);
+    return nan ? quiet_nan<T>() : m;
 }
 
 // LEAN: 1 = plain training rollout, 2 = the same with the delta log of the replica exchange (see k_rollout_lane).
@@ -348,204 +378,257 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
         bool dep_u = false;
         bool is_last = active;  // I am the last writer of my cell in this step: my value goes to the table
         QL_STAMP(0);
-        if (!any_company) {
-            // ---- quiet: update of transition t from the row as gathered, the value carried from the selection ------
-            row_nan = row_nan_lane<NV>(masked_row<MASKED>(row, valid));
-            if (active) {
-                T m = row_max_lane(masked_row<MASKED>(row, valid));
-                if (row_nan) m = quiet_nan<T>();
-                q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
-                df_pub_write(&lds.pub[par][ii], stamp, q1, p.a);
-            }
-        } else {
-            DfPub<T>* const pub_now = lds.pub[par];
-            const unsigned char* const cols_now = lds.pub_a[t & 3];
-            // ---- writers of my row in the step before: their final values bring the gathered row up to date (the
-            // gather ran beside their stores).  They all published before the barrier.
-            if (__any(active && m128_any(Wst))) {
-                M128 w = active ? Wst : m128_zero();
-                while (m128_any(w)) {  // ascending agent index: the highest writer of a column wins
-                    const int j = m128_pop_lowest(w);
-                    T v;
-                    int col;
-                    (void)df_pub_read(lds.pub[par ^ 1], lds.pub_a[(t + 3) & 3], j, stamp_prev, &v, &col);
-                    row_set_lane<T, NV>(row, col, v);
-                }
-            }
-            // ---- update of transition t: lower-indexed writers of the row I write / of the row my maximum is taken
-            // over (the reference's order)
-            const M128 S_low = m128_and(Ws, below);
-            const M128 N_low = p.term ? m128_zero() : (self_loop ? S_low : m128_and(Wn, below));
-            dep_u = active && (m128_any(S_low) || m128_any(N_low));
-            if (!__any(dep_u)) {
-                // nobody here waits for a value: the plain update (the company is higher-indexed, or only matters for
-                // the selection)
-                if (active) {
-                    T m = row_max_lane(masked_row<MASKED>(row, valid));
-                    if (row_nan_lane<NV>(masked_row<MASKED>(row, valid))) m = quiet_nan<T>();
-                    q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
-                    df_pub_write(&pub_now[ii], stamp, q1, p.a);
-                }
-            } else {
-                // Which lower writers of my row write MY cell (the latest of their values is what I update) -- the
-                // columns were published with the selection.
-                int n_sc = 0;   // lower writers of my cell
-                int hsc = -1;   // ... the highest of them
-                if (dep_u) {
-                    M128 w = S_low;
-                    while (m128_any(w)) {
-                        const int j = m128_pop_lowest(w);
-                        if ((int)cols_now[j] == p.a) { ++n_sc; hsc = j; }
-                    }
-                }
-                // nobody below me writes the row I read: every lower writer of my cell has my reward, my maximum and my
-                // termination flag (same state, same action, an environment whose outcome is a function of the two) --
-                // the chain is mine to compute, nothing to wait for
-                const bool local_chain = Env::kSameOutcome && !m128_any(N_low);
-                const bool waits = dep_u && !local_chain;
-                bool todo = active;
-                int spin = 0;
-                for (int round = 0; __any(todo) && !timed_out; ++round) {
-                    if (todo) {
-                        bool ready = true;
-                        T q0 = p.pred;
-                        // values of the lower writers of the row my maximum is taken over: the first two stay in
-                        // registers (nearly always all of them)
-                        T v0 = 0, v1 = 0;
-                        int c0 = 0, c1 = 0, cnt = 0;
-                        if (waits) {
-                            int col;
-                            if (hsc >= 0) ready = df_pub_read(pub_now, cols_now, hsc, stamp, &q0, &col);
-                            M128 w = N_low;
-                            while (m128_any(w)) {
-                                const int j = m128_pop_lowest(w);
-                                T v;
-                                ready &= df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
-                                if (cnt == 0) { v0 = v; c0 = col; }
-                                if (cnt == 1) { v1 = v; c1 = col; }
-                                ++cnt;
-                            }
-                        }
-                        if (ready) {
-                            // (patched in place: the selection below brings the row to its final state anyway, with the
-                            // writers' values in the same ascending order)
-                            if (cnt >= 1) row_set_lane<T, NV>(row, c0, v0);
-                            if (cnt >= 2) row_set_lane<T, NV>(row, c1, v1);
-                            if (cnt > 2) {
-                                M128 w = N_low;
-                                while (m128_any(w)) {
-                                    const int j = m128_pop_lowest(w);
-                                    T v;
-                                    int col;
-                                    (void)df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
-                                    row_set_lane<T, NV>(row, col, v);
-                                }
-                            }
-                            T m = row_max_lane(masked_row<MASKED>(row, valid));
-                            if (row_nan_lane<NV>(masked_row<MASKED>(row, valid))) m = quiet_nan<T>();
-                            const int reps = (dep_u && local_chain) ? n_sc + 1 : 1;
-                            T q = q0;
-                            for (int k = 0; k < reps; ++k) q = Td<T>::apply(q, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
-                            q1 = q;
-                            df_pub_write(&pub_now[ii], stamp, q1, p.a);
-                            todo = false;
-                        }
-                    }
-                    if (round) ++extra_rounds;
-                    if (++spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }  // never expected: every wave leaves, error reported
-                }
-                dep_total += dep_u ? 1ull : 0ull;
-            }
-            // the table receives the LAST value of a written cell: by the highest writer of the cell
-            M128 hi = active ? m128_andnot(m128_andnot(Ws, below), my_bit) : m128_zero();  // higher writers of my row
-            if (__any(m128_any(hi))) {
-                while (m128_any(hi)) {
-                    const int j = m128_pop_lowest(hi);
-                    is_last &= (int)cols_now[j] != p.a;
-                }
-            }
-        }
-        const float u_t = (float)u;
-        QL_STAMP(2);
-        // base_runtime.py:212,218-221 for transition t (staged episode log: see k_rollout_lane)
+        float u_t = 0.0f;
         unsigned ep_raw = 0;
         unsigned long long enders = 0;
         float ep_value = 0.0f;
-        if (active) {
-            acc += r_t;
-            enders = __ballot(term_t && (flags & FLAG_ACCOUNT));
-            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(enders >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)enders, 0u));
-            if (term_t) {
-                if (rank == 0) ep_raw = atomicAdd(&lds.ep_n, (unsigned)__popcll(enders));  // the first ending lane
-                ep_value = acc;
-                acc = 0.0f;
-            }
-        }
-        QL_STAMP(4);
-        // ---- selection of transition t+1 from row p.n after EVERY update of step t -----------------------------
-        if (!last) {
-            if (!any_company) {
-                // (the flag of the update's row serves: an own write into the row adds a NaN exactly when the new value
-                // is one and cannot remove one -- see k_rollout_lane)
-                if (self_loop) {
-                    row_set_lane<T, NV>(row, p.a, q1);
-                    row_nan |= q1 != q1;
+        // Update of transition t, accounting, selection of transition t+1: two copies of this code, one per answer to
+        // "does any agent of this wavefront share a row?" -- in ONE copy the branch arms that patch the row meet the
+        // quiet ones in front of the selection, and the merge costs the quiet path a register shuffle of the whole row.
+        auto body = [&](auto company_tag) {
+            constexpr bool COMPANY = decltype(company_tag)::value;
+            if constexpr (!COMPANY) {
+                // ---- quiet: update of transition t from the row as gathered, the value carried from the selection ------
+                row_nan = row_nan_lane<NV>(masked_row<MASKED>(row, valid));
+                if (active) {
+                    T m = row_max_lane(masked_row<MASKED>(row, valid));
+                    if (row_nan) m = quiet_nan<T>();
+                    q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
+                    df_pub_write(&lds.pub[par][ii], stamp, q1, p.a);
                 }
             } else {
-                // all writers of that row (any index); on a self-loop the other writers of row p.s, and my own value
                 DfPub<T>* const pub_now = lds.pub[par];
                 const unsigned char* const cols_now = lds.pub_a[t & 3];
-                const M128 others = m128_andnot(self_loop ? Ws : Wn, my_bit);
-                const bool dep_s = active && m128_any(others);
-                // the first two writers' values stay in registers (nearly always all of them)
-                T v0 = 0, v1 = 0;
-                int c0 = 0, c1 = 0, j0 = 0, j1 = 0, cnt = 0;
-                if (__any(dep_s)) {
-                    // wait until every writer this wavefront's selections depend on has published (updates never wait
-                    // for selections, so this cannot deadlock)
-                    for (int spin = 0; !timed_out; ++spin) {
-                        bool ready = true;
-                        cnt = 0;
-                        if (dep_s) {
-                            M128 w = others;
+                // ---- writers of my row in the step before: their final values bring the gathered row up to date (the
+                // gather ran beside their stores).  They all published before the barrier.
+                if (__any(active && m128_any(Wst))) {
+                    // (the two lowest side by side -- nearly always all of them; ascending agent index: the highest
+                    // writer of a column wins)
+                    int j0, j1;
+                    const int cnt = m128_two_lowest(active ? Wst : m128_zero(), &j0, &j1);
+                    T v0, v1;
+                    int c0, c1;
+                    (void)df_pub_read(lds.pub[par ^ 1], lds.pub_a[(t + 3) & 3], j0 >= 0 ? j0 : ii, stamp_prev, &v0, &c0);
+                    (void)df_pub_read(lds.pub[par ^ 1], lds.pub_a[(t + 3) & 3], j1 >= 0 ? j1 : ii, stamp_prev, &v1, &c1);
+                    if (cnt >= 1 && cnt <= 2) row_set_lane<T, NV>(row, c0, v0);
+                    if (cnt == 2) row_set_lane<T, NV>(row, c1, v1);
+                    if (cnt > 2) {
+                        M128 w = Wst;
+                        while (m128_any(w)) {
+                            const int j = m128_pop_lowest(w);
+                            T v;
+                            int col;
+                            (void)df_pub_read(lds.pub[par ^ 1], lds.pub_a[(t + 3) & 3], j, stamp_prev, &v, &col);
+                            row_set_lane<T, NV>(row, col, v);
+                        }
+                    }
+                }
+                // ---- update of transition t: lower-indexed writers of the row I write / of the row my maximum is taken
+                // over (the reference's order)
+                const M128 S_low = m128_and(Ws, below);
+                const M128 N_low = p.term ? m128_zero() : (self_loop ? S_low : m128_and(Wn, below));
+                dep_u = active && (m128_any(S_low) || m128_any(N_low));
+                if (!__any(dep_u)) {
+                    // nobody here waits for a value: the plain update (the company is higher-indexed, or only matters for
+                    // the selection)
+                    if (active) {
+                        T m = row_max_lane(masked_row<MASKED>(row, valid));
+                        if (row_nan_lane<NV>(masked_row<MASKED>(row, valid))) m = quiet_nan<T>();
+                        q1 = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
+                        df_pub_write(&pub_now[ii], stamp, q1, p.a);
+                    }
+                } else {
+                    // Which lower writers of my row write MY cell (the latest of their values is what I update) -- the
+                    // columns were published with the selection.  Up to two lower writers (nearly always all of them)
+                    // are looked at side by side: their LDS reads are in flight together.
+                    int n_sc = 0;   // lower writers of my cell
+                    int hsc = -1;   // ... the highest of them
+                    int n0 = -1, n1 = -1, nn = 0;  // lower writers of the row my maximum is taken over
+                    int cn0 = -1, cn1 = -1;        // ... and the columns they write
+                    if (dep_u) {
+                        int s0, s1;
+                        const int ns = m128_two_lowest(S_low, &s0, &s1);
+                        nn = m128_two_lowest(N_low, &n0, &n1);
+                        const int a_s0 = (int)cols_now[s0 >= 0 ? s0 : ii], a_s1 = (int)cols_now[s1 >= 0 ? s1 : ii];
+                        cn0 = n0 >= 0 ? (int)cols_now[n0] : -1;
+                        cn1 = n1 >= 0 ? (int)cols_now[n1] : -1;
+                        if (ns <= 2) {
+                            const bool m0 = ns >= 1 && a_s0 == p.a, m1 = ns >= 2 && a_s1 == p.a;
+                            n_sc = (m0 ? 1 : 0) + (m1 ? 1 : 0);
+                            hsc = m1 ? s1 : (m0 ? s0 : -1);
+                        } else {
+                            M128 w = S_low;
                             while (m128_any(w)) {
                                 const int j = m128_pop_lowest(w);
-                                T v;
-                                int col;
-                                ready &= df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
-                                if (cnt == 0) { v0 = v; c0 = col; j0 = j; }
-                                if (cnt == 1) { v1 = v; c1 = col; j1 = j; }
-                                ++cnt;
+                                if ((int)cols_now[j] == p.a) { ++n_sc; hsc = j; }
                             }
                         }
-                        if (!__any(!ready)) break;
-                        if (spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }
-                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    // nobody below me writes the row I read: every lower writer of my cell has my reward, my maximum and my
+                    // termination flag (same state, same action, an environment whose outcome is a function of the two) --
+                    // the chain is mine to compute, nothing to wait for
+                    const bool local_chain = Env::kSameOutcome && nn == 0;
+                    const bool waits = dep_u && !local_chain;
+                    const bool many = waits && nn > 2;  // (more lower writers on my read row than the registers hold)
+                    // the maximum over the columns nobody below me writes, once
+                    T rest;
+                    bool rest_nan;
+                    row_rest_lane<T, NV, M>(masked_row<MASKED>(row, valid), waits && !many ? cn0 : -1, waits && !many ? cn1 : -1,
+                                            &rest, &rest_nan);
+                    bool todo = active;
+                    int spin = 0;
+                    for (int round = 0; __any(todo) && !timed_out; ++round) {
+                        if (todo) {
+                            bool ready = true;
+                            T q0 = p.pred, v0 = 0, v1 = 0, m;
+                            if (waits) {
+                                int col;
+                                T qh;
+                                // (three independent reads: one LDS round trip)
+                                const bool ok_h = df_pub_read(pub_now, cols_now, hsc >= 0 ? hsc : ii, stamp, &qh, &col);
+                                const bool ok_0 = df_pub_read(pub_now, cols_now, n0 >= 0 ? n0 : ii, stamp, &v0, &col);
+                                const bool ok_1 = df_pub_read(pub_now, cols_now, n1 >= 0 ? n1 : ii, stamp, &v1, &col);
+                                ready = (hsc < 0 || ok_h) && (n0 < 0 || ok_0) && (n1 < 0 || ok_1);
+                                if (hsc >= 0) q0 = qh;
+                                if (many) {  // the generic form: every lower writer of the row, patched in place
+                                    M128 w = N_low;
+                                    while (m128_any(w)) {
+                                        const int j = m128_pop_lowest(w);
+                                        T v;
+                                        ready &= df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
+                                    }
+                                }
+                            }
+                            if (ready) {
+                                if (many) {
+                                    // (patched in place: the selection below brings the row to its final state anyway,
+                                    // with the writers' values in the same ascending order)
+                                    M128 w = N_low;
+                                    while (m128_any(w)) {
+                                        const int j = m128_pop_lowest(w);
+                                        T v;
+                                        int col;
+                                        (void)df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
+                                        row_set_lane<T, NV>(row, col, v);
+                                    }
+                                    m = row_max_np_lane<T, NV>(masked_row<MASKED>(row, valid));
+                                } else {
+                                    m = max_with_patches<T, M>(rest, rest_nan, valid, waits ? nn : 0, cn0, v0, cn1, v1);
+                                }
+                                const int reps = (dep_u && local_chain) ? n_sc + 1 : 1;
+                                T q = q0;
+                                for (int k = 0; k < reps; ++k) q = Td<T>::apply(q, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
+                                q1 = q;
+                                df_pub_write(&pub_now[ii], stamp, q1, p.a);
+                                todo = false;
+                            }
+                        }
+                        if (round) ++extra_rounds;
+                        if (++spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }  // never expected: every wave leaves, error reported
+                    }
+                    dep_total += dep_u ? 1ull : 0ull;
+                }
+                // the table receives the LAST value of a written cell: by the highest writer of the cell
+                M128 hi = active ? m128_andnot(m128_andnot(Ws, below), my_bit) : m128_zero();  // higher writers of my row
+                if (__any(m128_any(hi))) {
+                    int h0, h1;
+                    const int nh = m128_two_lowest(hi, &h0, &h1);
+                    const int a_h0 = (int)cols_now[h0 >= 0 ? h0 : ii], a_h1 = (int)cols_now[h1 >= 0 ? h1 : ii];
+                    if (nh >= 1) is_last &= a_h0 != p.a;
+                    if (nh >= 2) is_last &= a_h1 != p.a;
+                    if (nh > 2) {
+                        while (m128_any(hi)) {
+                            const int j = m128_pop_lowest(hi);
+                            is_last &= (int)cols_now[j] != p.a;
+                        }
                     }
                 }
-                // patches in ascending agent index (the highest writer of a column wins), my own write at its place
-                if (dep_s && cnt <= 2) {
-                    if (cnt >= 1 && j0 < ii) row_set_lane<T, NV>(row, c0, v0);
-                    if (cnt >= 2 && j1 < ii) row_set_lane<T, NV>(row, c1, v1);
-                    if (self_loop) row_set_lane<T, NV>(row, p.a, q1);
-                    if (cnt >= 1 && j0 > ii) row_set_lane<T, NV>(row, c0, v0);
-                    if (cnt >= 2 && j1 > ii) row_set_lane<T, NV>(row, c1, v1);
-                } else if (dep_s) {
-                    M128 w = self_loop ? Ws : Wn;
-                    while (m128_any(w)) {
-                        const int j = m128_pop_lowest(w);
-                        T v;
-                        int col;
-                        (void)df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
-                        row_set_lane<T, NV>(row, col, v);
-                    }
-                } else if (active && self_loop) {
-                    row_set_lane<T, NV>(row, p.a, q1);  // own write lands in the row I hold
-                }
-                row_nan = row_nan_lane<NV>(masked_row<MASKED>(row, valid));
             }
-            if (active) advance(row, valid, t + 1, x, thr_t1, row_nan);
-        }
+            u_t = (float)u;
+            QL_STAMP(2);
+            // base_runtime.py:212,218-221 for transition t (staged episode log: see k_rollout_lane)
+            if (active) {
+                acc += r_t;
+                enders = __ballot(term_t && (flags & FLAG_ACCOUNT));
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(enders >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)enders, 0u));
+                if (term_t) {
+                    if (rank == 0) ep_raw = atomicAdd(&lds.ep_n, (unsigned)__popcll(enders));  // the first ending lane
+                    ep_value = acc;
+                    acc = 0.0f;
+                }
+            }
+            QL_STAMP(4);
+            // ---- selection of transition t+1 from row p.n after EVERY update of step t -----------------------------
+            if (!last) {
+                if constexpr (!COMPANY) {
+                    // (the flag of the update's row serves: an own write into the row adds a NaN exactly when the new value
+                    // is one and cannot remove one -- see k_rollout_lane)
+                    if (__any(self_loop)) {  // (rare: behind a branch the whole wavefront can skip)
+                        if (self_loop) {
+                            row_set_lane<T, NV>(row, p.a, q1);
+                            row_nan |= q1 != q1;
+                        }
+                    }
+                } else {
+                    // all writers of that row (any index); on a self-loop the other writers of row p.s, and my own value
+                    DfPub<T>* const pub_now = lds.pub[par];
+                    const unsigned char* const cols_now = lds.pub_a[t & 3];
+                    const M128 others = m128_andnot(self_loop ? Ws : Wn, my_bit);
+                    const bool dep_s = active && m128_any(others);
+                    // the first two writers (nearly always all of them) are read side by side and stay in registers
+                    T v0 = 0, v1 = 0;
+                    int c0 = 0, c1 = 0, j0 = -1, j1 = -1;
+                    const int cnt = m128_two_lowest(others, &j0, &j1);
+                    if (__any(dep_s)) {
+                        // wait until every writer this wavefront's selections depend on has published (updates never wait
+                        // for selections, so this cannot deadlock)
+                        for (int spin = 0; !timed_out; ++spin) {
+                            bool ready = true;
+                            if (dep_s) {
+                                const bool ok_0 = df_pub_read(pub_now, cols_now, j0 >= 0 ? j0 : ii, stamp, &v0, &c0);
+                                const bool ok_1 = df_pub_read(pub_now, cols_now, j1 >= 0 ? j1 : ii, stamp, &v1, &c1);
+                                ready = (j0 < 0 || ok_0) && (j1 < 0 || ok_1);
+                                if (cnt > 2) {
+                                    M128 w = others;
+                                    while (m128_any(w)) {
+                                        const int j = m128_pop_lowest(w);
+                                        T v;
+                                        int col;
+                                        ready &= df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
+                                    }
+                                }
+                            }
+                            if (!__any(!ready)) break;
+                            if (spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    // patches in ascending agent index (the highest writer of a column wins), my own write at its place
+                    if (dep_s && cnt <= 2) {
+                        if (cnt >= 1 && j0 < ii) row_set_lane<T, NV>(row, c0, v0);
+                        if (cnt >= 2 && j1 < ii) row_set_lane<T, NV>(row, c1, v1);
+                        if (self_loop) row_set_lane<T, NV>(row, p.a, q1);
+                        if (cnt >= 1 && j0 > ii) row_set_lane<T, NV>(row, c0, v0);
+                        if (cnt >= 2 && j1 > ii) row_set_lane<T, NV>(row, c1, v1);
+                    } else if (dep_s) {
+                        M128 w = self_loop ? Ws : Wn;
+                        while (m128_any(w)) {
+                            const int j = m128_pop_lowest(w);
+                            T v;
+                            int col;
+                            (void)df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
+                            row_set_lane<T, NV>(row, col, v);
+                        }
+                    } else if (active && self_loop) {
+                        row_set_lane<T, NV>(row, p.a, q1);  // own write lands in the row I hold
+                    }
+                    row_nan = row_nan_lane<NV>(masked_row<MASKED>(row, valid));
+                }
+                if (active) advance(row, valid, t + 1, x, thr_t1, row_nan);
+            }
+        };
+        if (any_company) body(std::true_type{});
+        else body(std::false_type{});
         QL_STAMP(5);
         if (enders) {  // entry k of this flush window lands at log position ep_base + k
             const unsigned base = __builtin_amdgcn_readlane(ep_raw, __ffsll((long long)enders) - 1);
