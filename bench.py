@@ -285,7 +285,7 @@ def main() -> None:
     bpe = algorithmic_bytes_per_env_step(wl["actions"], wl["masked"])
     if persistent:
         # one launch per (chunk of a) call: the launch IS the step loop
-        kernel = "k_rollout_lane"
+        kernel = "k_rollout_df" if "k_rollout_df" in _lib.variant_symbol(int(samples[0].get("kernel_variant", 0))) else "k_rollout_lane"
         launches = sum(s["dominant_launches"] for s in samples)
         launch_s = sum(s["dominant_ms"] for s in samples) / max(1, launches) / 1e3
         units_per_launch = sum(s["dominant_env_steps"] for s in samples) / max(1, launches)
@@ -322,11 +322,17 @@ def main() -> None:
         timing = "HIP events around the whole stream region of one further call of the same K steps"
         kernel_note = (f"k_step_fast alone: {s0['dominant_ms'] / max(1, s0['dominant_launches']) * 1e3:.2f} us per launch over "
                        f"{s0['dominant_launches']} sampled launches; per-kernel split: profiles/")
-    traffic_profile = None  # HBM bytes from the PMC passes kept under profiles/ (NOT measured in this run)
+    # The kernel instantiation that ran (qe_rollout_stats.kernel_variant), as rocprofv3 names it.
+    env_name = "TttEnv" if wl.get("env") == "tictactoe" else "HashEnv"
+    variant = int(samples[0].get("kernel_variant", 0) or stats.get("kernel_variant", 0))
+    kernel_symbol = _lib.variant_symbol(variant, "float", env_name, algo.lanes_per_row())
+    # HBM bytes from the PMC passes kept under profiles/ -- NOT measured in this run: quoted only if the profile was
+    # taken on the same kernel instantiation (its symbol is recorded in the file, with the commit it was collected at).
+    traffic_profile = None
     try:
-        prof = json.loads((ROOT / "profiles" / "r02_traffic.json").read_text()).get(args.workload)
-        if prof:
-            traffic_profile = {"file": "profiles/r02_traffic.json", **prof}
+        prof = json.loads((ROOT / "profiles" / "r03_traffic.json").read_text()).get(args.workload)
+        if prof and prof.get("kernel_symbol") == kernel_symbol:
+            traffic_profile = {"file": "profiles/r03_traffic.json", **prof}
     except (OSError, ValueError, KeyError):
         pass
     line = {
@@ -356,6 +362,7 @@ def main() -> None:
         "roofline": {
             "bound": "hbm",
             "kernel": kernel,
+            "kernel_symbol": kernel_symbol,
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

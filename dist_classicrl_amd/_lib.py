@@ -44,6 +44,22 @@ def decode_variant(v: int) -> dict:
     }
 
 
+def variant_symbol(v: int, dtype: str = "float", env: str = "HashEnv", lanes_per_row: int = 4) -> str:
+    """The kernel instantiation behind ``kernel_variant`` as rocprofv3 prints it (without the ``void qe::`` prefix and
+    the argument list): what ``bench.py`` names in ``roofline.kernel`` and matches profile files against."""
+    d = decode_variant(v)
+    b = lambda x: "true" if x else "false"  # noqa: E731
+    if d["path"] == "persistent" and d["dataflow"]:
+        return f"k_rollout_df<{dtype}, qe::{env}, {d['nv']}, {b(d['masked'])}, {d['lean']}, {b(d['full'])}>"
+    if d["path"] == "persistent":
+        cap = 512 if d["cap512"] else 128
+        return (f"k_rollout_lane<{dtype}, qe::{env}, {d['nv']}, {cap}, {b(d['masked'])}, {d['lean']}, {b(d['help'])}, "
+                f"{b(d['full'])}, {b(d['light'])}>")
+    lc = lanes_per_row if env == "HashEnv" and lanes_per_row in (4, 8, 16) else 0
+    name = {"turnstile": "k_step_turn", "stepwise": "k_step_fast", "wide": "k_step_fast", "eval": "k_eval"}.get(d["path"], "?")
+    return f"{name}<{dtype}, qe::{env}, {lc}>" if name != "k_eval" else f"k_eval<{dtype}, qe::{env}>"
+
+
 class EngineError(RuntimeError):
     """The HIP engine reported a failure that has no closer Python equivalent."""
 

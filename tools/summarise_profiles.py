@@ -6,7 +6,7 @@ import shutil
 import sys
 from pathlib import Path
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = Path("gpurun_out") / f"prof_{tag}"
 dst = Path("profiles")
 
@@ -41,7 +41,28 @@ def pmc_sum(group, counter, kernel_substr, wl="headline"):
     return total, launches
 
 
-kern = "k_rollout_lane"
+import subprocess
+
+commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+if subprocess.run(["git", "status", "--porcelain", "--", "dist_classicrl_amd/csrc"], capture_output=True, text=True).stdout.strip():
+    commit += "+uncommitted kernel changes"
+
+
+def dominant(wl, prefix):
+    """Symbol (as bench.py's roofline.kernel_symbol spells it) and full name of the kernel with the largest total time
+    whose name starts with one of `prefix`."""
+    best = None
+    for row in csv.DictReader(open(one(f"{wl}_stats/**/*kernel_stats.csv"))):
+        name = row["Name"]
+        if any(("qe::" + p) in name for p in prefix) and (best is None or float(row["TotalDurationNs"]) > best[1]):
+            best = (name, float(row["TotalDurationNs"]), int(row["Calls"]), float(row["AverageNs"]))
+    name = best[0]
+    sym = name[name.index("qe::k_") + 4:name.index(">(") + 1]
+    return sym, best
+
+
+kern_sym, kern_row = dominant("headline", ("k_rollout_lane", "k_rollout_df"))
+kern = kern_sym.split("<")[0]
 fetch, n1 = pmc_sum("FETCH_SIZE", "FETCH_SIZE", kern)
 write, _ = pmc_sum("WRITE_SIZE", "WRITE_SIZE", kern)
 hit, _ = pmc_sum("TCC_HIT_sum_TCC_MISS_sum", "TCC_HIT_sum", kern)
@@ -54,7 +75,9 @@ out = {
     "headline": {
         "command": "rocprofv3 --kernel-trace --pmc <counter group> --output-format csv -- python3 bench.py --steps 20000 "
                    "--warmup 2000 --no-cpu-baseline (one pass per group: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)",
-        "kernel": "k_rollout_lane<float, HashEnv, 4, 128, false, 1, true, true, true> (the build without the general ordered path; 2 of the 94 launches took the build with it)",
+        "kernel_symbol": kern_sym,
+        "commit": commit,
+        "kernel_stats": {"calls": kern_row[2], "average_ns": kern_row[3], "total_ns": kern_row[1]},
         "launches": n1,
         "env_steps_all_launches": env_steps,
         "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
@@ -79,7 +102,8 @@ if glob.glob(str(src / "c3_pmc_FETCH_SIZE.log")):  # tools/collect_traffic_c3.sh
     out["c3"] = {
         "command": "QE_USE_GRAPH=0 rocprofv3 --kernel-trace --pmc <counter group> --output-format csv -- python3 bench.py --workload c3 "
                    "--steps 2000 --warmup 1000 --no-cpu-baseline (one pass per group, tools/collect_traffic_c3.sh)",
-        "kernel": "k_step_turn<float, HashEnv, 4>",
+        "kernel_symbol": "k_step_turn<float, qe::HashEnv, 4>",
+        "commit": commit,
         "launches": n1,
         "env_steps_all_launches": env_steps,
         "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
