@@ -238,7 +238,7 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
                     (long long)env->N, (int)e->A);
     // turnstile path: one launch per step, all workgroups resident, rows handed from agent to agent
     bool turn = false;
-    if (learn && !persistent && mode == QE_LEARN_ITER && (e->opt_path == 4 || (e->opt_path == 0 && TURN_AUTO))) {
+    if (learn && !persistent && (e->opt_path == 4 || (e->opt_path == 0 && TURN_AUTO))) {
         int& per_cu = e->turn_blocks_per_cu[env->p.kind & 3];
         if (per_cu == 0) {
             per_cu = turn_occupancy<T, Env>(e);

@@ -273,7 +273,9 @@ __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx
     if (sub == 0) {
         if (flags & FLAG_TURN) {
             turn_push(c, i, n, 1, t1, act);
-            if (tr.next_obs != n) turn_push(c, i, tr.next_obs, 0, t1, 0);
+            // (learn_vec: every agent READS the row of its next observation from the pre-step table, also when that is
+            // the row it writes -- the row's other writers must know, qe_step_turn.h)
+            if (tr.next_obs != n || c.mode == 1) turn_push(c, i, tr.next_obs, 0, t1, 0);
         } else if (!(flags & FLAG_NO_STAMPS)) {
             const int par1 = (int)(t1 & 1);
             touch(c.stamps, n, par1, TOUCH_W);

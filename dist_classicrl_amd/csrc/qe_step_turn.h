@@ -146,13 +146,15 @@ __device__ __forceinline__ void turn_walk2(const Ctx<T>& c, unsigned long long h
     uint32_t ls = (uint32_t)(head_s >> 32) == tag ? (uint32_t)head_s : 0u;
     uint32_t ln = sep && (uint32_t)(head_n >> 32) == tag ? (uint32_t)head_n : 0u;
     int64_t low_s = INT64_MAX, low_n = INT64_MAX;
-    for (int64_t guard = 0; ((ls | ln) & 0xFFFFFFu) != 0u && guard <= c.N; ++guard) {
+    for (int64_t guard = 0; ((ls | ln) & 0xFFFFFFu) != 0u && guard <= 2 * c.N; ++guard) {  // (learn_vec: up to two nodes per agent on a list)
         const uint32_t node_s = ls & 0xFFFFFFu, node_n = ln & 0xFFFFFFu;
         const int64_t js = (int64_t)((node_s - 1u) >> 1), jn = (int64_t)((node_n - 1u) >> 1);
         const int role_s = (int)((node_s - 1u) & 1u), role_n = (int)((node_n - 1u) & 1u);
         uint32_t nx_s = 0u, nx_n = 0u;
-        if (node_s) nx_s = js == i ? own_w : c.turn_next[turn_slot(c.N, par, js, role_s)];
-        if (node_n) nx_n = jn == i ? own_r : c.turn_next[turn_slot(c.N, par, jn, role_n)];
+        // (my own nodes: their links were loaded with the first batch.  Under learn_vec an agent whose next observation
+        // is the state it leaves has BOTH its nodes on one list)
+        if (node_s) nx_s = js == i ? (role_s ? own_w : own_r) : c.turn_next[turn_slot(c.N, par, js, role_s)];
+        if (node_n) nx_n = jn == i ? (role_n ? own_w : own_r) : c.turn_next[turn_slot(c.N, par, jn, role_n)];
         if (node_s) turn_visit(ws, low_s, ls, js, role_s, i, c.N, par);
         if (node_n) turn_visit(wn, low_n, ln, jn, role_n, i, c.N, par);
         ls = nx_s;
@@ -281,6 +283,78 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     const unsigned long long mine = __ballot(sub == 0);
                     if (__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u)) == 0u && sub == 0)
                         atomicAdd(&c.ctrl->involved_total, (unsigned long long)__popcll(mine));
+                }
+                if (c.mode == 1) {
+                    // ---- learn_vec (q_learning_optimal.py:819-891, np.add.at :235-250) on the lists: every agent forms
+                    // its increment from the PRE-STEP table; the increments reach a cell in agent order, each addition in
+                    // float64 rounded into the table dtype.  So: a reader of a written row tells the row's progress word
+                    // that it has read (its row load has returned: the maximum below depends on it); a writer waits until
+                    // ALL readers of its row have read and all lower writers have written, adds to the cell's current
+                    // value and advances the word; the selection waits for all writers of its row, as under learn_iter.
+                    const T m_pre = row_max_valid<LC>(row, valid, c.L);
+                    double inc;
+                    if constexpr (sizeof(T) == 4) inc = Td<float>::vec_inc(pred, r, m_pre, term, hyper);
+                    else inc = Td<double>::delta(pred, r, m_pre, term, hyper, true);
+                    if (sub == 0) {
+                        const unsigned long long one = 1ull | (unsigned long long)(__float_as_uint((float)inc) & opaque_zero());
+                        if (cont_n) atomicAdd(prog_n, one);          // I have read row n
+                        if (!sep && cont_s) atomicAdd(prog_s, one);  // ... which is row s: my reader node sits on its list
+                    }
+                    const int readers_s = ws.K - ws.writers;
+                    const int writers_sel = sep ? (cont_n ? wn.writers : 0) : ws.writers - 1;  // other writers of the row I select from
+                    const unsigned long long cols_sel = (sep ? wn.cols_other : ws.cols_other) | (sep ? 0ull : (1ull << (a < 63 ? a : 63)));
+                    int phase = 0;
+                    T q1 = pred;
+                    for (int spin = 0; phase < 2; ++spin) {
+                        if (spin >= TURN_SPIN_LIMIT) {
+                            if (sub == 0) c.ctrl->error = ERR_TURN_TIMEOUT;
+                            break;
+                        }
+                        if (phase == 0) {
+                            int ok = 1;
+                            if (sub == 0 && cont_s) {
+                                const uint32_t d = (uint32_t)rmw_read(prog_s);
+                                ok = (int)(d >> 16) == ws.lower_w && (int)(d & 0xFFFFu) == readers_s;
+                            }
+                            if (cont_s) ok = __shfl(ok, 0, W);
+                            if (ok) {
+                                if (sub == 0) {
+                                    // the cell's current value: the table's, if a lower writer has added to it in this step
+                                    const T cur = (ws.cols_lower & (1ull << (a < 63 ? a : 63))) ? rmw_read(c.q + cell) : pred;
+                                    q1 = (T)((double)cur + inc);
+                                    const uint32_t done = rmw_write(c.q + cell, q1);
+                                    log_delta(c, t, i, cell, (T)inc);
+                                    if (flags & FLAG_ACCOUNT) account(c, t, i, r, term);
+                                    if (cont_s) atomicAdd(prog_s, (1ull | (unsigned long long)(done & opaque_zero())) << 16);
+                                }
+                                phase = writers_sel > 0 ? 1 : 3;
+                                if (phase == 3) {
+                                    // nobody else writes the row I select from: what I hold (+ my own write) is the row
+                                    if (!sep) set_col4(row, sub, a, __shfl(q1, 0, W));
+                                    if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
+                                    phase = 2;
+                                }
+                            }
+                        }
+                        if (phase == 1) {
+                            int ok = 1;
+                            if (sub == 0) {
+                                const uint32_t d = (uint32_t)rmw_read(sep ? prog_n : prog_s);
+                                ok = (int)(d >> 16) == (sep ? wn.writers : ws.writers);
+                            }
+                            ok = __shfl(ok, 0, W);
+                            if (ok) {
+                                if (flags & FLAG_SELECT) {
+                                    patch_row4_rmw(row, c.q, n, c.ld, sub, cols_sel);
+                                    advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
+                                }
+                                phase = 2;
+                            }
+                        }
+                        if (phase < 2) __builtin_amdgcn_s_sleep(2);
+                    }
+                    TURN_CLK(4);
+                    return;
                 }
                 // the lowest toucher of its rows starts at once
                 const bool wait_s = cont_s && ws.lower > 0, wait_n = cont_n && wn.lower_w > 0;

@@ -115,8 +115,6 @@ SEEDED = [
 def test_tables_that_hold_nan_follow_the_reference(spec, chunks, dt, mode, sched, cells, tseed, path):
     if path == "persistent" and spec[1] > 512:
         pytest.skip("more than 512 agents: the persistent kernel does not apply")
-    if path == "turnstile" and mode != "iter":
-        pytest.skip("the turnstile path orders learn_iter only")
     S, A = (19683, 9) if spec[0] == "ttt" else (spec[2], spec[3])
     q0 = _nan_table(S, A, dt, cells, tseed)
     want = run_oracle_chunks(spec, chunks, dt, sched, mode, q0=q0)
@@ -214,8 +212,6 @@ def test_closed_loop_through_nan_matches_reference_golden(case, path):
     mode = "iter" if learn_fn == "learn" else "vec"
     if path == "persistent" and spec[1] > 512:
         pytest.skip("more than 512 agents: the persistent kernel does not apply")
-    if path == "turnstile" and mode != "iter":
-        pytest.skip("the turnstile path orders learn_iter only")
     g = np.load(GOLDEN / "nan_regime.npz")
     want, base = golden_nan_trace(g, name, spec, dt, cells, tseed)
     got = _run_product_chunks(spec, chunks, dt, sched, mode, path, q0=base if cells else None)

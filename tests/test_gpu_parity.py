@@ -246,8 +246,6 @@ def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="a
         from dist_classicrl_amd import _lib
         algo.set_engine_option(_lib.OPT_TURN_FORWARD, 0)
         path = "turnstile"
-    if path == "turnstile" and mode != "iter":
-        pytest.skip("learn_vec: the turnstile path orders learn_iter only (the engine would take its automatic choice)")
     if path == "wide_listed":  # the compacted-list rounds (automatic from 16384 agents), seven rounds
         from dist_classicrl_amd import _lib
         algo.set_rollout_path("wide")
@@ -359,6 +357,10 @@ def test_rollout_matches_oracle_seeded(spec, steps, dt, mode, path):
         pytest.skip("more than 512 agents: the persistent kernel does not apply")
     want = run_oracle_trace(spec, steps, dt, "const", mode)
     got = _run_product_trace(spec, steps, dt, "const", mode, path=path)
+    if path in ("turnstile", "turnstile_reread") and 512 < spec[1] <= 8192:
+        # learn_iter AND learn_vec: one launch per vector step, rows handed over inside it (qe_step_turn.h)
+        from dist_classicrl_amd import _lib
+        assert _lib.decode_variant(got["stats"]["kernel_variant"])["path"] == "turnstile"
     assert np.array_equal(got["actions"], want["actions"])
     assert np.array_equal(got["q"], want["q"])
     assert np.array_equal(got["history"], want["history"])
