@@ -144,6 +144,8 @@ def main() -> None:
     ap.add_argument("--turn-forward", type=int, default=1, choices=[0, 1],
                     help="turnstile path (513 .. ~60 000 agents): 0 = no value forwarding in the progress words "
                          "(measurement switch, results are identical)")
+    ap.add_argument("--turn-poll", type=int, default=0, choices=[0, 1],
+                    help="turnstile path: 1 = progress words polled with sc1 loads, 0 = with returning atomics (measurement switch)")
     ap.add_argument("--lane-ordered-path", type=int, default=0, choices=[0, 1, 2, 3],
                     help="persistent path, up to 128 agents: 0 = automatic, 1 = the dataflow kernel, 2 = the build with the "
                          "general ordered path, 3 = the sparse build (measurement switch, results are identical)")
@@ -206,6 +208,8 @@ def main() -> None:
                              ExponentialSchedule(1.0, 0.01, 0.995), learn_mode=args.mode)
     if not args.turn_forward:
         algo.set_engine_option(_lib.OPT_TURN_FORWARD, 0)
+    if args.turn_poll:
+        algo.set_engine_option(_lib.OPT_TURN_POLL, 1)
     if args.lane_ordered_path:
         algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, args.lane_ordered_path)
     if n >= 16384:

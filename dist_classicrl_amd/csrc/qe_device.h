@@ -227,6 +227,7 @@ __device__ __forceinline__ bool row_has_nan(const Row4<T>& row, uint32_t valid4,
     bool mine = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) mine |= ((valid4 >> j) & 1u) && row.v[j] != row.v[j];
+    if constexpr (dpp_width(LC)) return group_or<LC>(mine ? 1u : 0u) != 0u;  // (compile-time widths: a few DPP moves)
     const unsigned long long b = __ballot(mine);
     if (L >= 64) return b != 0ull;
     const int base = (int)__lane_id() & ~(L - 1);

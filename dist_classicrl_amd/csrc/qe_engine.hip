@@ -680,6 +680,7 @@ int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_HOST_BLOCK && (value == 0 || value == 1)) { e->opt_host_block = (int)value; return QE_OK; }
     if (option == QE_OPT_LANE_ORDERED_PATH && value >= 0 && value <= 3) { e->opt_lane_ordered = (int)value; return QE_OK; }
     if (option == QE_OPT_TURN_FORWARD && (value == 0 || value == 1)) { e->opt_turn_forward = (int)value; return QE_OK; }
+    if (option == QE_OPT_TURN_POLL && (value == 0 || value == 1)) { e->opt_turn_poll = (int)value; return QE_OK; }
     return qe_fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 

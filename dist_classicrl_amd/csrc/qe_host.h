@@ -167,6 +167,7 @@ struct qe_engine {
     int opt_timing = 1;  // QE_OPT_EVENT_TIMING: bracket rollouts with HIP events (persistent path: off = in-kernel clock only)
     int opt_host_block = 1;  // QE_OPT_HOST_BLOCK: persistent rollouts publish through the host result block
     int opt_turn_forward = 1;  // QE_OPT_TURN_FORWARD: value forwarding in the progress words of the turnstile path
+    int opt_turn_poll = 0;     // QE_OPT_TURN_POLL: 1 = progress words are polled with sc1 loads, 0 (default) = with returning atomics
     int opt_lane_ordered = 0;  // QE_OPT_LANE_ORDERED_PATH: 0 = automatic, 1 = dataflow kernel, 2 = full build, 3 = sparse build
     int lane_light = -1;       // automatic choice for the next launch (same values; -1: not decided yet)
     unsigned long long seq_ctr = 0;

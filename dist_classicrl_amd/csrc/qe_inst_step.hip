@@ -13,8 +13,10 @@ void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& e
     const dim3 grid(grid_for(c.N * c.L, FAST_BLOCK)), block(FAST_BLOCK);
     if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample], e->stream);
     if (c.turn_next) {  // turnstile path: the whole vector step is this one launch (qe_step_turn.h)
-        hipLaunchKernelGGL((k_step_turn<T, Env, LC>), grid, block, 0, e->stream, c, ev,
-                           flags | FLAG_TURN | (e->opt_turn_forward ? 0 : FLAG_TURN_NO_FORWARD));
+        const int tflags = flags | FLAG_TURN | (e->opt_turn_forward ? 0 : FLAG_TURN_NO_FORWARD) |
+                           (e->opt_turn_poll ? 0 : FLAG_TURN_ATOMIC_POLL);
+        if (c.mode == QE_LEARN_VEC) hipLaunchKernelGGL((k_step_turn<T, Env, LC, true>), grid, block, 0, e->stream, c, ev, tflags);
+        else hipLaunchKernelGGL((k_step_turn<T, Env, LC, false>), grid, block, 0, e->stream, c, ev, tflags);
         if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
         ++sl.launches;
         return;
@@ -163,7 +165,11 @@ int turn_occupancy(const qe_engine* e) {
     hipError_t err = hipErrorInvalidValue;
     auto ask = [&](auto lc) {
         constexpr int LC = decltype(lc)::value;
-        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_step_turn<T, Env, LC>, FAST_BLOCK, 0);
+        // (the smaller of the two builds' answers: one capacity for both update modes)
+        int nb_iter = 0, nb_vec = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_iter, k_step_turn<T, Env, LC, false>, FAST_BLOCK, 0);
+        if (err == hipSuccess) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_vec, k_step_turn<T, Env, LC, true>, FAST_BLOCK, 0);
+        nb = nb_iter < nb_vec ? nb_iter : nb_vec;
     };
     if constexpr (std::is_same<Env, HashEnv>::value) {  // (same choice as launch_step_any)
         switch (e->L) {

@@ -48,6 +48,7 @@ constexpr int FLAG_PRESTAGED = 256;      // ordered path: the caller has staged 
 constexpr int FLAG_VEC_INC_READY = 128;  // VEC, wide mode: the increments of the involved agents are already in vinc
 constexpr int FLAG_TURN = 1024;           // turnstile path: touches are registered on per-row lists (qe_step_turn.h)
 constexpr int FLAG_TURN_NO_FORWARD = 2048;  // turnstile path: always re-read written columns from the table (experiment switch)
+constexpr int FLAG_TURN_ATOMIC_POLL = 4096; // turnstile path: poll progress words with returning atomics instead of sc1 loads
 constexpr uint32_t TOK_INF = 0xFFFFFFFFu;
 constexpr unsigned ERR_EMPTY_CHOICE = 3u;  // Ctrl::error: a fused selection found no selectable action
 

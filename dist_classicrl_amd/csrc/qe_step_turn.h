@@ -65,6 +65,16 @@ __device__ __forceinline__ double rmw_read(double* p) {
     return __longlong_as_double((long long)__hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(p), z,
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// Poll of a progress word: a returning atomic OR with zero (FLAG_TURN_ATOMIC_POLL, the default), or a
+// `global_load_dwordx2 sc1` (relaxed agent-scope atomic load: bypasses the CU's L1, single-copy atomic for the naturally
+// aligned 8 bytes) -- the form MI355X_MICROARCH.md measures as valid for polling a counter that other workgroups advance
+// with agent-scope atomic adds; a stale answer could only make a waiter poll again (the word only counts up within a
+// step).  Round 3 measured the two against each other on one box: c3 26.7 / 26.85, c5 18.1 / 18.05, c4 shard 20.9 / 20.95 us
+// per step -- the link of a chain is not shortened by a cheaper poll.
+__device__ __forceinline__ unsigned long long poll_word(unsigned long long* p, int flags) {
+    if (flags & FLAG_TURN_ATOMIC_POLL) return rmw_read(p);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // store at the coherence point; the returned old value tells the caller when it has been performed
 __device__ __forceinline__ uint32_t rmw_write(float* p, float v) {
     return __hip_atomic_exchange(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED,
@@ -219,8 +229,11 @@ __device__ __forceinline__ uint32_t fwd_bits(T v) {
 #define TURN_CLK_START() do {} while (0)
 #endif
 
-template <typename T, class Env, int LC = 0>
+// VEC: the learn_vec build (its ordering rules are different code; compiled apart so that neither build carries the
+// other's registers: together they cost the learn_iter kernel a quarter of its occupancy and 500 scalar spills).
+template <typename T, class Env, int LC = 0, bool VEC = false>
 __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, int flags) {
+    c.mode = VEC ? 1 : 0;
     const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
     const int64_t i = gl >> c.lshift;
     const int sub = (int)(gl & (c.L - 1));
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     if (__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u)) == 0u && sub == 0)
                         atomicAdd(&c.ctrl->involved_total, (unsigned long long)__popcll(mine));
                 }
-                if (c.mode == 1) {
+                if constexpr (VEC) {
                     // ---- learn_vec (q_learning_optimal.py:819-891, np.add.at :235-250) on the lists: every agent forms
                     // its increment from the PRE-STEP table; the increments reach a cell in agent order, each addition in
                     // float64 rounded into the table dtype.  So: a reader of a written row tells the row's progress word
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                         if (phase == 0) {
                             int ok = 1;
                             if (sub == 0 && cont_s) {
-                                const uint32_t d = (uint32_t)rmw_read(prog_s);
+                                const uint32_t d = (uint32_t)poll_word(prog_s, flags);
                                 ok = (int)(d >> 16) == ws.lower_w && (int)(d & 0xFFFFu) == readers_s;
                             }
                             if (cont_s) ok = __shfl(ok, 0, W);
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                         if (phase == 1) {
                             int ok = 1;
                             if (sub == 0) {
-                                const uint32_t d = (uint32_t)rmw_read(sep ? prog_n : prog_s);
+                                const uint32_t d = (uint32_t)poll_word(sep ? prog_n : prog_s, flags);
                                 ok = (int)(d >> 16) == (sep ? wn.writers : ws.writers);
                             }
                             ok = __shfl(ok, 0, W);
@@ -386,13 +399,13 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                         uint32_t up_s = 0u, up_n = 0u;  // last value written to row s / row n (upper halves)
                         if (sub == 0) {
                             if (wait_s) {
-                                const unsigned long long d64 = rmw_read(prog_s);
+                                const unsigned long long d64 = poll_word(prog_s, flags);
                                 const uint32_t d = (uint32_t)d64;
                                 up_s = (uint32_t)(d64 >> 32);
                                 ok &= (int)((d >> 16) + (d & 0xFFFFu)) == ws.lower;
                             }
                             if (wait_n) {
-                                const unsigned long long d64 = rmw_read(prog_n);
+                                const unsigned long long d64 = poll_word(prog_n, flags);
                                 up_n = (uint32_t)(d64 >> 32);
                                 ok &= (int)((uint32_t)d64 >> 16) == wn.lower_w;
                             }
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                         int ok = 1;
                         uint32_t up = 0u;
                         if (sub == 0) {
-                            const unsigned long long d64 = rmw_read(sep ? prog_n : prog_s);
+                            const unsigned long long d64 = poll_word(sep ? prog_n : prog_s, flags);
                             up = (uint32_t)(d64 >> 32);
                             ok = (int)((uint32_t)d64 >> 16) == (sep ? wn.writers : ws.writers);
                         }

@@ -123,7 +123,9 @@ enum qe_option { QE_OPT_ROLLOUT_PATH = 0, QE_OPT_USE_GRAPH = 1 /* 1 (default): r
                                                  build (rows rarely shared; full wavefronts only, else 1) */,
                  QE_OPT_TURN_FORWARD = 7 /* turnstile path, fp32 tables: 1 (default) = a row's progress word carries the value its last
                                             writer stored, successors whose view of the row can differ in that one column only take it
-                                            from their poll; 0 = they always re-read the table (measurement switch) */ };
+                                            from their poll; 0 = they always re-read the table (measurement switch) */,
+                 QE_OPT_TURN_POLL = 8 /* turnstile path: 0 (default) = progress words are polled with returning atomics, 1 = with
+                                         agent-scope loads (sc1); measured equal, kept as a measurement switch */ };
 int qe_set_option(qe_engine* e, int32_t option, int64_t value);
 
 /* ---- Q-table I/O ----------------------------------------------------------------------------
