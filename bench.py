@@ -329,7 +329,7 @@ def main() -> None:
     # The kernel instantiation that ran (qe_rollout_stats.kernel_variant), as rocprofv3 names it.
     env_name = "TttEnv" if wl.get("env") == "tictactoe" else "HashEnv"
     variant = int(samples[0].get("kernel_variant", 0) or stats.get("kernel_variant", 0))
-    kernel_symbol = _lib.variant_symbol(variant, "float", env_name, int(algo.lanes_per_row))
+    kernel_symbol = _lib.variant_symbol(variant, "float", env_name, int(algo.lanes_per_row), args.mode == "vec")
     # HBM bytes from the PMC passes kept under profiles/ -- NOT measured in this run: quoted only if the profile was
     # taken on the same kernel instantiation (its symbol is recorded in the file, with the commit it was collected at).
     traffic_profile = None

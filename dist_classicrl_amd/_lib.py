@@ -45,7 +45,7 @@ def decode_variant(v: int) -> dict:
     }
 
 
-def variant_symbol(v: int, dtype: str = "float", env: str = "HashEnv", lanes_per_row: int = 4) -> str:
+def variant_symbol(v: int, dtype: str = "float", env: str = "HashEnv", lanes_per_row: int = 4, vec: bool = False) -> str:
     """The kernel instantiation behind ``kernel_variant`` as rocprofv3 prints it (without the ``void qe::`` prefix and
     the argument list): what ``bench.py`` names in ``roofline.kernel`` and matches profile files against."""
     d = decode_variant(v)
@@ -58,6 +58,8 @@ def variant_symbol(v: int, dtype: str = "float", env: str = "HashEnv", lanes_per
                 f"{b(d['full'])}, {b(d['light'])}>")
     lc = lanes_per_row if env == "HashEnv" and lanes_per_row in (4, 8, 16) else 0
     name = {"turnstile": "k_step_turn", "stepwise": "k_step_fast", "wide": "k_step_fast", "eval": "k_eval"}.get(d["path"], "?")
+    if name == "k_step_turn":
+        return f"k_step_turn<{dtype}, qe::{env}, {lc}, {b(vec)}>"
     return f"{name}<{dtype}, qe::{env}, {lc}>" if name != "k_eval" else f"k_eval<{dtype}, qe::{env}>"
 
 

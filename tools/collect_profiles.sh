@@ -3,7 +3,7 @@
 # bench.py's roofline block and profiles/ are built from.  Usage: tools/collect_profiles.sh <tag>
 # Output: gpurun_out/prof_<tag>/...; summarise locally with tools/summarise_profiles.py <tag>.
 set -uo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -25,7 +25,7 @@ fi
 # 4. kernel stats of the step-wise / wide shapes with eager launches (QE_USE_GRAPH=0: the profiles describe the
 #    kernels, whose durations do not depend on how they are launched; bench.py's own numbers use graph replay)
 export QE_USE_GRAPH=0
-for wl in c3 c5 wide; do
+for wl in c2 c3 c4shard c5 wide; do
     steps=4000; [ "$wl" = wide ] && steps=400
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${wl}_stats" -- python3 $ROOT/bench.py --workload $wl --steps $steps --warmup 4000 --no-cpu-baseline > "$OUT/${wl}_stats.log" 2>&1 || exit 1
 done

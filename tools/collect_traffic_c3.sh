@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX: the three PMC passes (one counter group per run, --kernel-trace only) over the c3 workload
 # (turnstile path, eager launches), for profiles/<tag>_traffic.json's "c3" entry.  Usage: tools/collect_traffic_c3.sh <tag>
 set -uo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"

@@ -1,6 +1,6 @@
 set -uo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/prof_r02b
+OUT=$ROOT/gpurun_out/prof_${1:-r03b}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export QE_USE_GRAPH=0

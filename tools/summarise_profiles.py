@@ -25,8 +25,8 @@ def bench_line(log):
     raise SystemExit(f"no bench line in {log}")
 
 
-for wl in ("headline", "c3", "c5", "c4shard", "wide"):
-    if wl == "c4shard" and not glob.glob(str(src / "c4shard_stats.log")):
+for wl in ("headline", "c2", "c3", "c5", "c4shard", "wide"):
+    if not glob.glob(str(src / f"{wl}_stats.log")):
         continue
     shutil.copy(one(f"{wl}_stats/**/*kernel_stats.csv"), dst / f"{tag}_{wl}_kernel_stats.csv")
     json.dump(bench_line(src / f"{wl}_stats.log"), open(dst / f"{tag}_{wl}_bench_under_rocprof.json", "w"), indent=1)
@@ -102,7 +102,7 @@ if glob.glob(str(src / "c3_pmc_FETCH_SIZE.log")):  # tools/collect_traffic_c3.sh
     out["c3"] = {
         "command": "QE_USE_GRAPH=0 rocprofv3 --kernel-trace --pmc <counter group> --output-format csv -- python3 bench.py --workload c3 "
                    "--steps 2000 --warmup 1000 --no-cpu-baseline (one pass per group, tools/collect_traffic_c3.sh)",
-        "kernel_symbol": "k_step_turn<float, qe::HashEnv, 4>",
+        "kernel_symbol": "k_step_turn<float, qe::HashEnv, 4, false>",
         "commit": commit,
         "launches": n1,
         "env_steps_all_launches": env_steps,
