@@ -40,7 +40,7 @@ def _apply(q, cells, deltas):
     np.add.at(q.reshape(-1), cells, deltas)
 
 
-def _worker(rank, world, port, out_dir, overlap, one_launch=False):
+def _worker(rank, world, port, out_dir, overlap, one_launch=False, gathered=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dist_classicrl_amd.distributed.delta_sync import DeltaSync
@@ -59,7 +59,14 @@ def _worker(rank, world, port, out_dir, overlap, one_launch=False):
 
     # one_launch: fixed-size logs like the engine's (slot = step * n + agent), so count == capacity
     cap = CHUNK * N_PER_RANK if one_launch else S * A
-    sync = DeltaSync(cap, "cpu", apply_fn, overlap=overlap, apply_skip_fn=apply_skip_fn if one_launch else None)
+    def apply_gathered_fn(g, capacity, count, world_, rank_):  # the engine's whole apply step (qe_delta_apply_gathered_dev)
+        assert capacity == cap and world_ == world and rank_ == rank
+        others = np.concatenate([g[r, :count].numpy() for r in range(world) if r != rank])
+        order = np.argsort(others[:, 0], kind="stable")  # by cell; within a cell (rank, slot) order
+        _apply(run.q, others[order, 0], others[order, 1].view(np.float32))
+
+    sync = DeltaSync(cap, "cpu", apply_fn, overlap=overlap, apply_skip_fn=apply_skip_fn if one_launch else None,
+                     apply_gathered_fn=apply_gathered_fn if gathered else None)
     for k in range(CHUNKS):
         cells, deltas = _run_chunk(run, k)
         # every rank must exchange the same record count: pad with (cell 0, +0.0) no-ops
@@ -78,15 +85,16 @@ def _worker(rank, world, port, out_dir, overlap, one_launch=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize(("world", "overlap", "one_launch"),
-                         [(2, False, False), (2, True, False), (2, True, True), (3, True, True), (3, False, False)])
-def test_replica_sync_matches_single_process_simulation(tmp_path, world, overlap, one_launch):
+@pytest.mark.parametrize(("world", "overlap", "one_launch", "gathered"),
+                         [(2, False, False, False), (2, True, False, False), (2, True, True, False), (3, True, True, False),
+                          (3, False, False, False), (2, True, True, True), (3, True, False, True)])
+def test_replica_sync_matches_single_process_simulation(tmp_path, world, overlap, one_launch, gathered):
     from oracle import c_oracle
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap, one_launch), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap, one_launch, gathered), nprocs=world, join=True)
     got = [np.load(tmp_path / f"q{r}.npy") for r in range(world)]
 
     # single-process simulation of the same protocol: without overlap the other ranks' records are
