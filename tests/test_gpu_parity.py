@@ -225,19 +225,16 @@ def test_learn_vec_many_collisions_stay_exact():
 
 
 # ------------------------------------------------------------------------------- closed loop
-PATHS = ["stepwise", "persistent", "persistent_light", "wide", "wide_listed", "turnstile", "turnstile_reread"]
+# (every run below collects an action trace, and a traced rollout of up to 512 agents runs the GENERIC build of the
+# persistent kernel whatever QE_OPT_LANE_ORDERED_PATH says: the builds untraced rollouts get -- sparse, dataflow, full
+# -- are compared with the oracle in tests/test_gpu_shipped_builds.py)
+PATHS = ["stepwise", "persistent", "wide", "wide_listed", "turnstile", "turnstile_reread"]
 
 
 def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="auto"):
     Algo, Runtime, _, _ = _product()
     env = make_device_env(spec)
     algo = Algo(env.state_size, env.action_size, gamma, seed=seed, dtype=np.dtype(dt))
-    if path == "persistent_light":  # the persistent kernel's build without the general ordered path
-        if env.num_agents > 128 or env.num_agents % 64 or dt != "f4" or mode != "iter":
-            pytest.skip("the light build exists for float32 learn_iter rollouts of 64 or 128 agents")
-        from dist_classicrl_amd import _lib
-        algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, 1)
-        path = "persistent"
     if path == "persistent" and (env.action_size > 64 or env.num_agents > 512):
         pytest.skip("more than 512 agents / 64 actions: the persistent kernel does not apply")
     if path == "turnstile_reread":  # the turnstile path without value forwarding in the progress words
@@ -353,7 +350,7 @@ def test_rollout_matches_reference_golden_at_scale(case, path):
 )
 @pytest.mark.parametrize("path", PATHS)
 def test_rollout_matches_oracle_seeded(spec, steps, dt, mode, path):
-    if path in ("persistent", "persistent_light") and spec[1] > 512:
+    if path == "persistent" and spec[1] > 512:
         pytest.skip("more than 512 agents: the persistent kernel does not apply")
     want = run_oracle_trace(spec, steps, dt, "const", mode)
     got = _run_product_trace(spec, steps, dt, "const", mode, path=path)
