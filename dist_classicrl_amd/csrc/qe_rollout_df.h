@@ -605,11 +605,15 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                     }
                     // patches in ascending agent index (the highest writer of a column wins), my own write at its place
                     if (dep_s && cnt <= 2) {
-                        if (cnt >= 1 && j0 < ii) row_set_lane<T, NV>(row, c0, v0);
-                        if (cnt >= 2 && j1 < ii) row_set_lane<T, NV>(row, c1, v1);
-                        if (self_loop) row_set_lane<T, NV>(row, p.a, q1);
-                        if (cnt >= 1 && j0 > ii) row_set_lane<T, NV>(row, c0, v0);
-                        if (cnt >= 2 && j1 > ii) row_set_lane<T, NV>(row, c1, v1);
+                        // (three column replacements at most, each a compare-and-select over the whole row: j0 < j1, so
+                        // they go in that order; my own write -- on a self-loop -- only counts where no HIGHER writer has
+                        // written my column, and then its place in the order does not matter)
+                        if (cnt >= 1) row_set_lane<T, NV>(row, c0, v0);
+                        if (cnt >= 2) row_set_lane<T, NV>(row, c1, v1);
+                        const bool mine_wins = self_loop && !((cnt >= 1 && j0 > ii && c0 == p.a) || (cnt >= 2 && j1 > ii && c1 == p.a));
+                        if (__any(mine_wins)) {
+                            if (mine_wins) row_set_lane<T, NV>(row, p.a, q1);
+                        }
                     } else if (dep_s) {
                         M128 w = self_loop ? Ws : Wn;
                         while (m128_any(w)) {
