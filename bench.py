@@ -146,6 +146,9 @@ def main() -> None:
                          "(measurement switch, results are identical)")
     ap.add_argument("--turn-poll", type=int, default=0, choices=[0, 1],
                     help="turnstile path: 1 = progress words polled with sc1 loads, 0 = with returning atomics (measurement switch)")
+    ap.add_argument("--stamp-hash-bits", type=int, default=0,
+                    help="step-wise / wide paths: log2 of the hashed touch-counter slots (0 = automatic, 1 = one slot per "
+                         "row; measurement switch, results are identical)")
     ap.add_argument("--lane-ordered-path", type=int, default=0, choices=[0, 1, 2, 3],
                     help="persistent path, up to 128 agents: 0 = automatic, 1 = the dataflow kernel, 2 = the build with the "
                          "general ordered path, 3 = the sparse build (measurement switch, results are identical)")
@@ -210,6 +213,8 @@ def main() -> None:
         algo.set_engine_option(_lib.OPT_TURN_FORWARD, 0)
     if args.turn_poll:
         algo.set_engine_option(_lib.OPT_TURN_POLL, 1)
+    if args.stamp_hash_bits:
+        algo.set_engine_option(_lib.OPT_STAMP_HASH_BITS, args.stamp_hash_bits)
     if args.lane_ordered_path:
         algo.set_engine_option(_lib.OPT_LANE_ORDERED_PATH, args.lane_ordered_path)
     if n >= 16384:

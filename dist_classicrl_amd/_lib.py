@@ -30,6 +30,7 @@ OPT_HOST_BLOCK = 5
 OPT_LANE_ORDERED_PATH = 6
 OPT_TURN_FORWARD = 7
 OPT_TURN_POLL = 8
+OPT_STAMP_HASH_BITS = 9
 PATH_AUTO, PATH_STEPWISE, PATH_PERSISTENT, PATH_WIDE, PATH_TURNSTILE = 0, 1, 2, 3, 4
 
 ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_INDEX = -1, -2, -3, -4, -5

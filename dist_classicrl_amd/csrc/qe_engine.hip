@@ -681,6 +681,11 @@ int qe_set_option(qe_engine* e, int32_t option, int64_t value) {
     if (option == QE_OPT_LANE_ORDERED_PATH && value >= 0 && value <= 3) { e->opt_lane_ordered = (int)value; return QE_OK; }
     if (option == QE_OPT_TURN_FORWARD && (value == 0 || value == 1)) { e->opt_turn_forward = (int)value; return QE_OK; }
     if (option == QE_OPT_TURN_POLL && (value == 0 || value == 1)) { e->opt_turn_poll = (int)value; return QE_OK; }
+    if (option == QE_OPT_STAMP_HASH_BITS && value >= 0 && value <= 30) {
+        if (e->slots[0].busy || e->slots[1].busy) return qe_fail(QE_ERR_INVALID, "a rollout is in flight");
+        e->opt_stamp_bits = (int)value;  // (the counters are all zero between calls: any slot function may take over)
+        return QE_OK;
+    }
     return qe_fail(QE_ERR_INVALID, "unknown option %d / value %lld", (int)option, (long long)value);
 }
 

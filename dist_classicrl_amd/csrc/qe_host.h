@@ -167,6 +167,7 @@ struct qe_engine {
     int opt_timing = 1;  // QE_OPT_EVENT_TIMING: bracket rollouts with HIP events (persistent path: off = in-kernel clock only)
     int opt_host_block = 1;  // QE_OPT_HOST_BLOCK: persistent rollouts publish through the host result block
     int opt_turn_forward = 1;  // QE_OPT_TURN_FORWARD: value forwarding in the progress words of the turnstile path
+    int opt_stamp_bits = 0;    // QE_OPT_STAMP_HASH_BITS: 0 = automatic, else log2 of the hashed touch-counter slots
     int opt_turn_poll = 0;     // QE_OPT_TURN_POLL: 1 = progress words are polled with sc1 loads, 0 (default) = with returning atomics
     int opt_lane_ordered = 0;  // QE_OPT_LANE_ORDERED_PATH: 0 = automatic, 1 = dataflow kernel, 2 = full build, 3 = sparse build
     int lane_light = -1;       // automatic choice for the next launch (same values; -1: not decided yet)
@@ -261,11 +262,21 @@ inline EnvCtx make_envctx(const qe_engine* e, const qe_env_params* p, const uint
     return ev;
 }
 
+// Touch counters of the step-wise / wide kernels: one slot per row, or -- tables of more than 2^22 rows, whose counter array
+// (16 B per row) would not stay in the Infinity Cache -- 2^21 hashed slots (QE_OPT_STAMP_HASH_BITS forces a size).
+inline uint32_t stamp_hash_mask(const qe_engine* e) {
+    if (e->opt_stamp_bits == 1) return 0u;  // one slot per row, whatever the size
+    int bits = e->opt_stamp_bits ? e->opt_stamp_bits : (e->S > ((int64_t)1 << 22) ? 21 : 0);
+    while (bits > 0 && ((int64_t)1 << bits) > e->S) --bits;  // (the array holds S slots)
+    return bits > 0 ? (uint32_t)(((int64_t)1 << bits) - 1) : 0u;
+}
+
 template <typename T>
 Ctx<T> base_ctx(qe_engine* e, int64_t N) {
     Ctx<T> c{};
     c.q = (T*)e->q; c.S = e->S; c.A = e->A; c.ld = e->ld; c.L = e->L; c.lshift = e->lshift;
     c.N = N; c.stamps = e->stamps; c.ctrl = e->ctrl;
+    c.stamp_mask = stamp_hash_mask(e);
     c.thr = (const QE_AS4 unsigned long long*)e->thr.p; c.lr = (const QE_AS4 double*)e->lr.p;
     c.seed_lo = (uint32_t)e->seed; c.seed_hi = (uint32_t)(e->seed >> 32);
     c.agent_offset = e->agent_offset; c.step0 = e->step_ctr; c.gamma = e->gamma;

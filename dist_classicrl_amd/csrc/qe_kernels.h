@@ -110,6 +110,9 @@ struct Ctx {
     int32_t A, ld, L, lshift;
     int64_t N;
     unsigned long long* stamps;  // [S][2] touch counters: writers << 32 | readers
+    uint32_t stamp_mask;         // != 0: the counters of row x live at slot mix32(x) & stamp_mask (large tables: a counter
+                                 // table that stays in the Infinity Cache; rows that collide count as shared -- they go
+                                 // through the ordered path, which keys on the rows themselves: exact, a few more agents there)
     uint32_t* inv_bitmap;   // ceil(N/32) words
     int32_t* inv_list;      // N
     double* vinc;           // N: VEC-mode increments of involved agents
@@ -166,9 +169,13 @@ struct Ctx {
 // different one reads it (each agent touches a row at most once per step: its read of row n is
 // dropped when n == s).  Rows that are only read by several agents are not contested.
 constexpr unsigned long long TOUCH_W = 1ull << 32, TOUCH_R = 1ull;
-__device__ __forceinline__ void touch(unsigned long long* stamps, int64_t row, int par,
-                                      unsigned long long kind) {
-    atomicAdd(&stamps[2 * row + par], kind);  // result unused -> non-returning global_atomic_add_x2
+template <typename T>
+__device__ __forceinline__ int64_t stamp_slot(const Ctx<T>& c, int64_t row) {
+    return c.stamp_mask ? (int64_t)(mix32((uint32_t)row) & c.stamp_mask) : row;
+}
+template <typename T>
+__device__ __forceinline__ void touch(const Ctx<T>& c, int64_t row, int par, unsigned long long kind) {
+    atomicAdd(&c.stamps[2 * stamp_slot(c, row) + par], kind);  // result unused -> non-returning global_atomic_add_x2
 }
 __device__ __forceinline__ bool contested(unsigned long long v) {
     const uint32_t w = (uint32_t)(v >> 32), r = (uint32_t)v;
@@ -279,8 +286,8 @@ __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx
             if (tr.next_obs != n || c.mode == 1) turn_push(c, i, tr.next_obs, 0, t1, 0);
         } else if (!(flags & FLAG_NO_STAMPS)) {
             const int par1 = (int)(t1 & 1);
-            touch(c.stamps, n, par1, TOUCH_W);
-            if (tr.next_obs != n) touch(c.stamps, tr.next_obs, par1, TOUCH_R);
+            touch(c, n, par1, TOUCH_W);
+            if (tr.next_obs != n) touch(c, tr.next_obs, par1, TOUCH_R);
         }
         if (c.trace) c.trace[t1 * c.N + i] = act;
         replay_put(c, t1, i, n, act, tr.reward, tr.next_obs, tr.terminated);
@@ -341,8 +348,8 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
     if (flags & FLAG_LEARN) {
         const int par = (int)(t & 1);
         const int32_t s = c.s[i];
-        const unsigned long long cs = c.stamps[2 * (int64_t)s + par];
-        const unsigned long long cn = c.stamps[2 * (int64_t)n + par];
+        const unsigned long long cs = c.stamps[2 * stamp_slot(c, s) + par];
+        const unsigned long long cn = c.stamps[2 * stamp_slot(c, n) + par];
         if (contested(cs) || (n != s && contested(cn))) {  // shared row: defer to the ordered path
             if (sub == 0) {
                 atomicOr(&c.inv_bitmap[i >> 5], 1u << (i & 31));
@@ -362,8 +369,8 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_fast(Ctx<T> c, EnvCtx ev, i
         const bool term = c.term[i] != 0;
         const T m = row_max_valid<LC>(row, valid, c.L);
         if (sub == 0) {
-            c.stamps[2 * (int64_t)s + par] = 0ull;
-            if (n != s) c.stamps[2 * (int64_t)n + par] = 0ull;
+            c.stamps[2 * stamp_slot(c, s) + par] = 0ull;
+            if (n != s) c.stamps[2 * stamp_slot(c, n) + par] = 0ull;
         }
         const int64_t cell = (int64_t)s * c.ld + a;
         const T q0 = (flags & FLAG_PRED_FROM_TABLE) ? c.q[cell] : c.pred[i];
@@ -916,8 +923,8 @@ __device__ void slow_body(const Ctx<T>& c, const EnvCtx& ev, int flags, long lon
         }
         if (flags & FLAG_ACCOUNT) account(c, t, i, g.r, g.term);
         if (!(flags & FLAG_NO_STAMPS)) {
-            c.stamps[2 * (int64_t)g.s + par] = 0ull;
-            c.stamps[2 * (int64_t)g.n + par] = 0ull;
+            c.stamps[2 * stamp_slot(c, g.s) + par] = 0ull;
+            c.stamps[2 * stamp_slot(c, g.n) + par] = 0ull;
         }
         if (c.tok) {  // whatever the token rounds left posted for these agents
             c.tok[g.s] = TOK_INF; c.tok[c.S + g.s] = TOK_INF;
@@ -1141,8 +1148,8 @@ __device__ __forceinline__ void advance_postponed(const Ctx<T>& c, const EnvCtx&
     const int32_t s = c.s[i], n = c.n[i];
     if (sub == 0) {
         const int par = (int)(t & 1);
-        c.stamps[2 * (int64_t)s + par] = 0ull;
-        c.stamps[2 * (int64_t)n + par] = 0ull;
+        c.stamps[2 * stamp_slot(c, s) + par] = 0ull;
+        c.stamps[2 * stamp_slot(c, n) + par] = 0ull;
         atomicAnd(&c.adv_bitmap[i >> 5], ~(1u << (i & 31)));
     }
     if (flags & FLAG_SELECT) {
@@ -1336,8 +1343,8 @@ __global__ void k_touch_batch(Ctx<T> c) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.N) return;
     const int32_t s = c.s[i], n = c.n[i];
-    touch(c.stamps, s, 0, TOUCH_W);
-    if (n != s) touch(c.stamps, n, 0, TOUCH_R);
+    touch(c, s, 0, TOUCH_W);
+    if (n != s) touch(c, n, 0, TOUCH_R);
 }
 
 // ---- environments driven from the host ----------------------------------------------------------

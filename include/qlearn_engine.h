@@ -125,7 +125,11 @@ enum qe_option { QE_OPT_ROLLOUT_PATH = 0, QE_OPT_USE_GRAPH = 1 /* 1 (default): r
                                             writer stored, successors whose view of the row can differ in that one column only take it
                                             from their poll; 0 = they always re-read the table (measurement switch) */,
                  QE_OPT_TURN_POLL = 8 /* turnstile path: 0 (default) = progress words are polled with returning atomics, 1 = with
-                                         agent-scope loads (sc1); measured equal, kept as a measurement switch */ };
+                                         agent-scope loads (sc1); measured equal, kept as a measurement switch */,
+                 QE_OPT_STAMP_HASH_BITS = 9 /* step-wise / wide paths: touch counters in 2^value hashed slots instead of one per
+                                               row (rows that collide count as shared: a few more agents on the ordered path,
+                                               same results); 0 (default) = automatic: 21 bits for tables of more than 2^22 rows,
+                                               1 = one slot per row whatever the size */ };
 int qe_set_option(qe_engine* e, int32_t option, int64_t value);
 
 /* ---- Q-table I/O ----------------------------------------------------------------------------

@@ -365,6 +365,76 @@ def test_rollout_matches_oracle_seeded(spec, steps, dt, mode, path):
     assert np.array_equal(got["agent_rewards"], want["agent_rewards"])
 
 
+@pytest.mark.parametrize("bits", [4, 9, 14])
+@pytest.mark.parametrize("path", ["stepwise", "wide", "wide_listed"])
+@pytest.mark.parametrize(("spec", "steps", "dt", "mode"), [
+    (("hash", 1024, 5000, 16, False), 30, "f4", "iter"),
+    (("hash", 4096, 300000, 8, False), 12, "f4", "iter"),
+    (("hash", 3000, 40000, 16, False), 10, "f8", "iter"),
+    (("hash", 2500, 40000, 16, True), 12, "f4", "vec"),
+    (("ttt", 700), 30, "f8", "iter"),
+])
+def test_hashed_touch_counters_change_nothing(spec, steps, dt, mode, path, bits):
+    """QE_OPT_STAMP_HASH_BITS: the touch counters of the step-wise / wide kernels in 2^bits hashed slots (automatic for
+    tables of more than 2^22 rows).  Rows that collide in the hash count as shared and take the ordered path, which keys on
+    the rows themselves -- with 16 slots nearly every agent does: results must not move."""
+    from dist_classicrl_amd import _lib
+
+    want = run_oracle_trace(spec, steps, dt, "const", mode)
+    Algo, Runtime, _, _ = _product()
+    env = make_device_env(spec)
+    algo = Algo(env.state_size, env.action_size, 0.99, seed=0, dtype=np.dtype(dt))
+    algo.set_engine_option(_lib.OPT_STAMP_HASH_BITS, bits)
+    if path == "wide_listed":
+        algo.set_rollout_path("wide")
+        algo.set_engine_option(_lib.OPT_LISTED_MIN_AGENTS, 1)
+        algo.set_engine_option(_lib.OPT_TOKEN_ROUNDS, 7)
+    else:
+        algo.set_rollout_path(path)
+    lr_p, eps_p = schedule_params("const")
+    rt = Runtime(algo, make_schedule(lr_p), make_schedule(eps_p), learn_mode=mode)
+    rt.trace_actions = True
+    _avg, history, _env, sd = rt.run_steps(steps, env, None)
+    assert np.array_equal(rt.last_trace, want["actions"])
+    assert np.array_equal(np.asarray(algo.q_table), want["q"])
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    # ... and the batch API, whose kernels count touches in the same slots
+    from oracle.qlearn_oracle import OracleQLearning
+
+    rng = np.random.default_rng(bits)
+    S, A, n = env.state_size, env.action_size, 900
+    batch = (rng.integers(0, min(S, 50), n), rng.integers(0, A, n), rng.random(n).astype(np.float32),
+             rng.integers(0, min(S, 50), n), rng.random(n) < 0.1)
+    ref = OracleQLearning(S, A, 0.99, seed=0, dtype=np.dtype(dt))
+    ref.q_table = np.array(want["q"])
+    ref.learn(*[np.array(b) for b in batch], 0.1)
+    algo.learn(*batch, 0.1)
+    assert np.array_equal(np.asarray(algo.q_table), ref.q_table)
+
+
+@pytest.mark.parametrize("path", ["stepwise", "wide"])
+def test_large_table_takes_hashed_counters_automatically(path):
+    """More than 2^22 rows: 2^21 hashed counter slots without being asked (the 16-B-per-row counter array of a 1e7-row
+    table would not stay in the Infinity Cache); bit-exact against the C oracle."""
+    from oracle import c_oracle
+
+    n, S, A, steps = 3000, 5_000_000, 16, 40
+    Algo, Runtime, envs, sch = _product()
+    algo = Algo(S, A, 0.99, seed=0)
+    algo.set_rollout_path(path)
+    rt = Runtime(algo, sch.ExponentialSchedule(0.1, 1e-5, 0.995), sch.ExponentialSchedule(1.0, 0.01, 0.995))
+    rt.trace_actions = True
+    _avg, history, _, sd = rt.run_steps(steps, envs.HashTabularEnv(n, S, A, seed=1), None)
+    ref = c_oracle.CHashRollout(n, S, A, dtype=np.float32)
+    eps, _ = c_oracle.exp_schedule(1.0, 0.01, 0.995, n, steps)
+    lr, _ = c_oracle.exp_schedule(0.1, 1e-5, 0.995, n, steps)
+    want = ref.run(eps, lr, trace=True)
+    assert np.array_equal(rt.last_trace, want["actions"])
+    assert np.array_equal(np.asarray(algo.q_table), ref.q)
+    assert np.array_equal(np.array(history, dtype=np.float32), want["history"])
+    assert np.array_equal(sd["states"], ref.obs)
+
+
 @pytest.mark.parametrize("path", ["stepwise", "persistent", "wide", "turnstile"])
 def test_rollout_without_selectable_action_raises_like_the_reference(path):
     """A NaN row maximum leaves `np.where(row == max)` empty and the reference's `random.choice` raises
