@@ -70,6 +70,8 @@ class GpuRolloutQLearning(BaseRuntime):
             raise ValueError(msg)
         self.learn_mode = learn_mode
         self.last_stats = None  # accumulated qe_rollout_stats of the latest run_steps call
+        self._as_list = None    # returns of the call in progress as Python floats (see _rollout)
+        self._run_sum = np.zeros(1, dtype=np.float32)
         self.delta_sync = None  # dist_classicrl_amd.distributed.DeltaSync (multi-GPU replicas)
         self.sync_every = 100   # vector steps between two replica exchanges (BASELINE config 4)
         self._since_sync = 0    # vector steps logged since the last exchange (the cadence runs across calls)
@@ -133,6 +135,11 @@ class GpuRolloutQLearning(BaseRuntime):
             ret = np.empty(cnt, dtype=np.float32)
             lib.qe_episode_log(algo.handle, cnt, _lib.ptr(step_idx, C.c_int32), None, _lib.ptr(ret, C.c_float))
             history.append(ret)
+            if self._as_list is not None:
+                # Python floats and the running float32 sum chunk by chunk: under the launches that follow instead of
+                # behind the last one (130 000 returns of a 20 000-step call: 2 ms)
+                self._as_list.extend(ret.tolist())
+                self._run_sum = np.cumsum(np.concatenate((self._run_sum, ret)), dtype=np.float32)[-1:]
             if done:
                 step_idx += done
             ep_steps.append(step_idx)
@@ -140,8 +147,12 @@ class GpuRolloutQLearning(BaseRuntime):
             total[f] += getattr(st, f)
         self._variants.add(int(st.kernel_variant))
 
-    def _rollout(self, env, steps, learn):
+    def _rollout(self, env, steps, learn, as_list=False):
+        """Returns ``(returns, step of each return)``; with ``as_list`` the returns are also left as a list of Python floats
+        in ``self._as_list`` and their sequential float32 sum in ``self._run_sum[0]`` (single_thread_runtime.py:67)."""
         lib = _lib.load()
+        self._as_list = [] if as_list else None
+        self._run_sum = np.zeros(1, dtype=np.float32)
         algo = self.algorithm
         n = env.num_agents
         env._resident = None  # the device state moves on
@@ -308,9 +319,14 @@ class GpuRolloutQLearning(BaseRuntime):
                     sync.flush()
             reward_history = rets.tolist()
         else:
-            rets, _ = self._rollout(env, steps, learn=True)
-            reward_history = self._history(rets)
-            total = _sequential_sum(rets)
+            as_list = self.history_type == "float"
+            rets, _ = self._rollout(env, steps, learn=True, as_list=as_list)
+            if as_list:
+                reward_history, total = self._as_list, (self._run_sum[0] if len(self._as_list) else 0)
+                self._as_list = None
+            else:
+                reward_history = self._history(rets)
+                total = _sequential_sum(rets)
             state_dict = env.state_dict()
         state_dict["episode_rewards"] = reward_history
         # not part of the reference's dict (single_thread_runtime.py:70-75): what an exact resume in a

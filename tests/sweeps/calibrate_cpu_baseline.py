@@ -2,11 +2,11 @@
 same environment objects and injected draws, to show that the oracle's single-core speed is a fair
 stand-in for the reference's single_thread runtime.
 
-    PYTHONPATH=/root/reference/src PYTHONDONTWRITEBYTECODE=1 python tools/calibrate_cpu_baseline.py
+    PYTHONPATH=/root/reference/src PYTHONDONTWRITEBYTECODE=1 python tests/sweeps/calibrate_cpu_baseline.py
 """
 import json, os, sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import numpy as np
 from dist_classicrl.algorithms.base_algorithms.q_learning_optimal import OptimalQLearningBase
 from dist_classicrl.algorithms.runtime.base_runtime import BaseRuntime
@@ -70,7 +70,7 @@ for n, S, A, masked in [(128, 1_000_000, 16, False), (128, 10_000, 8, False), (1
         "reference_env_steps_per_s": [float(x) for x in rs], "oracle_env_steps_per_s": [float(x) for x in os_],
         "median_ratio_oracle_over_reference": float(o / r),
         "per_round_ratio": [float(b / a) for a, b in zip(rs, os_)]}
-out = Path(__file__).resolve().parents[1] / "profiles" / "r02_cpu_calibration.json"
-json.dump({"tool": "tools/calibrate_cpu_baseline.py (build container, one pinned core, interleaved rounds)",
+out = Path(__file__).resolve().parents[2] / "profiles" / "r02_cpu_calibration.json"
+json.dump({"tool": "tests/sweeps/calibrate_cpu_baseline.py (build container, one pinned core, interleaved rounds)",
            "rounds": ROUNDS, "results": results}, open(out, "w"), indent=1)
 print("written", out)

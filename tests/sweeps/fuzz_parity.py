@@ -1,10 +1,10 @@
 """Randomised parity sweep on the GPU box (not part of the test suite): random shapes, dtypes, learn
 modes, schedules and rollout paths, product vs the NumPy oracle, everything compared bit for bit.
-Usage: python tools/fuzz_parity.py <seconds> [seed] [path].  Prints every failing configuration.
+Usage: python tests/sweeps/fuzz_parity.py <seconds> [seed] [path].  Prints every failing configuration.
 `path` = a rollout path of tests/test_gpu_parity.py (traced runs), or persistent_df / persistent_full / persistent_sparse: plain
 training rollouts of up to 128 agents WITHOUT an action trace through the dataflow kernel / the full build / the sparse build
 (QE_OPT_LANE_ORDERED_PATH 1 / 2 / 3), cut into random run_steps calls -- the instantiations a user gets."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
 np.seterr(all="ignore")
@@ -81,7 +81,11 @@ while time.time() < t_end:
     path = str(rng.choice(["auto", "stepwise", "persistent", "wide", "wide_listed", "turnstile", "turnstile"]))
     if only_path:
         path = only_path
-    cfg = (spec, steps, dt, mode, sched, path)
+    if path in ("stepwise", "wide", "wide_listed"):  # hashed touch counters: 2^bits slots (1 = one per row)
+        os.environ["QE_TEST_STAMP_BITS"] = str(int(rng.choice([1, 2, 5, 9, 13])))
+    else:
+        os.environ.pop("QE_TEST_STAMP_BITS", None)
+    cfg = (spec, steps, dt, mode, sched, path, os.environ.get("QE_TEST_STAMP_BITS"))
     try:
         try:
             want = run_oracle_trace(spec, steps, dt, sched, mode)

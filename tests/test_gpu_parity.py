@@ -8,6 +8,8 @@
 Nothing here reads /root/reference (it does not exist on the GPU box).
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -250,6 +252,9 @@ def _run_product_trace(spec, steps, dt, sched, mode, gamma=0.99, seed=0, path="a
         algo.set_engine_option(_lib.OPT_TOKEN_ROUNDS, 7)  # >= 6: lists are used
     else:
         algo.set_rollout_path(path)
+    if os.environ.get("QE_TEST_STAMP_BITS"):  # tests/sweeps/fuzz_parity.py: hashed touch counters of a random size
+        from dist_classicrl_amd import _lib
+        algo.set_engine_option(_lib.OPT_STAMP_HASH_BITS, int(os.environ["QE_TEST_STAMP_BITS"]))
     lr_p, eps_p = schedule_params(sched)
     rt = Runtime(algo, make_schedule(lr_p), make_schedule(eps_p), learn_mode=mode)
     rt.trace_actions = True
