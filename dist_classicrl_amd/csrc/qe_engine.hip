@@ -247,18 +247,17 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
         turn = turn_fits(e, env->N, per_cu);
     }
     if (turn) {
-        const size_t words = (size_t)env->N * 4;
-        HIP_TRY(env->turn_next.ensure(words));
-        HIP_TRY(env->turn_prog.ensure(words));
-        c.turn_next = env->turn_next.p; c.turn_prog = env->turn_prog.p;
-        // list heads carry a 32-bit step tag and are never cleared: zero them before a tag can repeat
-        if (((e->turn_epoch + (unsigned long long)steps + 2ull) >> 31) != (e->turn_epoch >> 31) && e->stamps_hold_lists)
-            HIP_TRY(hipMemsetAsync(e->stamps, 0, (size_t)e->S * 2 * sizeof(unsigned long long), e->stream));
+        HIP_TRY(env->turn_next.ensure((size_t)env->N * 4));
+        // one 64-byte record per (row, step parity); they carry a 32-bit step tag and are never cleared per step:
+        // zeroed when allocated and before a tag can repeat
+        const size_t recs = (size_t)e->S * 2;
+        const bool fresh = e->turn_rows.cap < recs;
+        HIP_TRY(e->turn_rows.ensure(recs));
+        if (fresh || ((e->turn_epoch + (unsigned long long)steps + 2ull) >> 31) != (e->turn_epoch >> 31))
+            HIP_TRY(hipMemsetAsync(e->turn_rows.p, 0, e->turn_rows.cap * sizeof(TurnRow), e->stream));
+        c.turn_next = env->turn_next.p; c.turn_rows = e->turn_rows.p;
         c.turn_epoch = e->turn_epoch;
         e->turn_epoch += (unsigned long long)steps + 2ull;  // tags of this call: epoch .. epoch + steps
-        e->stamps_hold_lists = true;
-    } else if (learn && !persistent) {
-        if (int rc = stamps_as_counters(e)) return rc;
     }
     // wide mode: exact sequential updates, many agents, ordered path spread over the chip
     const bool wide = learn && !persistent && !turn &&
@@ -648,6 +647,7 @@ int qe_destroy(qe_engine* e) {
     if (e->stamps) (void)hipFree(e->stamps);
     if (e->ctrl) (void)hipFree(e->ctrl);
     if (e->tok) (void)hipFree(e->tok);
+    e->turn_rows.release();
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     e->slots[0].release(); e->slots[1].release();
@@ -899,7 +899,6 @@ static int learn_launch(qe_engine* e, int64_t n, double lr, bool masked, int32_t
             hipLaunchKernelGGL(k_learn_large<T>, dim3(1), dim3(64), 0, e->stream, c, ev, lr);
             return;
         }
-        (void)stamps_as_counters(e);
         hipLaunchKernelGGL(k_touch_batch<T>, dim3(grid_for(n, 256)), dim3(256), 0, e->stream, c);
         const int flags = FLAG_LEARN | FLAG_PRED_FROM_TABLE;
         hipLaunchKernelGGL((k_step_fast<T, HostEnv>), dim3(grid_for(n * e->L, FAST_BLOCK)), dim3(FAST_BLOCK), 0, e->stream, c, ev, flags);
@@ -1007,7 +1006,7 @@ int qe_env_destroy(qe_env* env) {
     (void)hipStreamSynchronize(env->e->stream);
     env->s.release(); env->a.release(); env->n.release(); env->list.release(); env->pend_list.release(); env->r.release();
     env->acc.release(); env->term.release(); env->pred.release(); env->aux.release();
-    env->bitmap.release(); env->adv_bitmap.release(); env->turn_next.release(); env->turn_prog.release(); env->masks.release(); env->vinc.release();
+    env->bitmap.release(); env->adv_bitmap.release(); env->turn_next.release(); env->masks.release(); env->vinc.release();
     delete env;
     return QE_OK;
 }

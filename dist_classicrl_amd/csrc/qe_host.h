@@ -156,8 +156,8 @@ struct qe_engine {
     uint32_t agent_offset = 0;
     int num_cus = 64;
     int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
-    unsigned long long turn_epoch = 1;  // turnstile path: list tag of the next call's step 0 (0 = the touch counters' rest value)
-    bool stamps_hold_lists = false;     // the touch-counter array holds turnstile list heads (cleared before counters use it)
+    unsigned long long turn_epoch = 1;  // turnstile path: record tag of the next call's step 0 (0 = a cleared record)
+    DevBuf<TurnRow> turn_rows;          // turnstile path: [S][2] touchers of a row per step parity, allocated on first use
     int turn_blocks_per_cu[4] = {0, 0, 0, 0};  // resident workgroups of k_step_turn per CU, by environment kind (0: not yet asked)
     hipStream_t debug_stream = nullptr;        // qe_debug_occupy_cus
     int opt_graph = 1; // QE_OPT_USE_GRAPH
@@ -237,8 +237,7 @@ struct qe_env {
     DevBuf<float> r, acc;
     DevBuf<uint8_t> term, pred, masks;
     DevBuf<uint32_t> aux, bitmap, adv_bitmap;
-    DevBuf<uint32_t> turn_next;            // turnstile path: [2][N][2], allocated on first use
-    DevBuf<unsigned long long> turn_prog;  // turnstile path: [2][N][2] progress words
+    DevBuf<uint32_t> turn_next;            // turnstile path: [2][N][2] overflow-list links, allocated on first use
     DevBuf<double> vinc;
     // host copy of (observations, env-internal state, running returns) left by the latest rollout's
     // result block; valid until anything else changes the device state
@@ -308,15 +307,6 @@ inline bool turn_fits(const qe_engine* e, int64_t N, int blocks_per_cu) {
     const int64_t cus = (int64_t)e->num_cus - e->num_cus / TURN_RESERVE_DIV;
     return N <= 60000 && blocks_per_cu > 0 && blocks <= cus * blocks_per_cu && e->ld <= 256;
 }
-// The touch-counter array doubles as the turnstile path's list heads; the counters' kernels expect zeros.
-inline int stamps_as_counters(qe_engine* e) {
-    if (e->stamps_hold_lists) {
-        HIP_TRY(hipMemsetAsync(e->stamps, 0, (size_t)e->S * 2 * sizeof(unsigned long long), e->stream));
-        e->stamps_hold_lists = false;
-    }
-    return QE_OK;
-}
-
 // one launch per rollout on one CU, one agent per lane with its whole row in registers (qe_rollout_lane.h)
 inline bool persistent_path(const qe_engine* e, const qe_env* env, int learn) {
     return learn && env->N <= LANE_MAX_AGENTS && e->ld <= 64 && (e->opt_path == 0 || e->opt_path == 2);

@@ -179,7 +179,6 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                                                            long long steps, int flags) {
     static_assert(LEAN == 1 || LEAN == 2, "plain training rollouts only");
     using M = typename LaneMask<NV>::type;
-    constexpr int NLOAD = NV * (int)(sizeof(T) / 4);  // 16-byte loads of one row gather
     constexpr int WT = DF_WT;
     __shared__ DfLds<T> lds;
     const unsigned long long clk0 = wall_clock64();
