@@ -195,17 +195,19 @@ __device__ __forceinline__ void turn_walk2(const Ctx<T>& c, unsigned long long h
     }
 }
 
-// Coherent re-read of the columns in `cols` (see TurnWalk) of a row held in registers.
+// Coherent re-read of a row held in registers where it can differ from the table: the lane's four columns, if `cols`
+// (see TurnWalk) names one of them.  All four are requested together -- one memory round trip (column by column, each
+// behind its own test, they were four); a column nobody else writes in this step comes back as the lane holds it.
 template <typename T>
 __device__ __forceinline__ void patch_row4_rmw(Row4<T>& r, T* q, int64_t row, int ld, int sub, unsigned long long cols) {
     const int c0 = 4 * sub;
     if (c0 >= ld) return;
     uint32_t m4 = c0 < 60 ? (uint32_t)(cols >> c0) & 0xFu : ((cols >> 63) ? 0xFu : 0u);
     if (c0 == 60) m4 = ((uint32_t)(cols >> 60) & 0x7u) | ((cols >> 63) ? 0x8u : 0u);
+    if (m4 == 0u) return;
     T* p = q + row * ld + c0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if ((m4 >> j) & 1u) r.v[j] = rmw_read(p + j);
+    const T v0 = rmw_read(p), v1 = rmw_read(p + 1), v2 = rmw_read(p + 2), v3 = rmw_read(p + 3);
+    r.v[0] = v0; r.v[1] = v1; r.v[2] = v2; r.v[3] = v3;
 }
 
 // Value forwarding (fp32 tables): the upper half of a row's progress word carries the value its most recent
@@ -404,7 +406,9 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                             phase = 3;
                         }
                     }
-                    if (phase == 3) {
+                    // (selections wait while an agent of this wavefront has its update ahead: see the learn_iter loop below)
+                    const bool update_ahead = __any(phase == 0);
+                    if (phase == 3 && !update_ahead) {
                         if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
                         phase = 2;
                     }
@@ -443,29 +447,32 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     int ok = 1;
                     uint32_t up_s = 0u, up_n = 0u;  // last value written to row s / row n (upper halves)
                     if (sub == 0) {
+                        // (both polls in flight together)
+                        unsigned long long ds64 = 0ull, dn64 = 0ull;
+                        if (wait_s) ds64 = poll_word(prog_s, flags);
+                        if (wait_n) dn64 = poll_word(prog_n, flags);
                         if (wait_s) {
-                            const unsigned long long d64 = poll_word(prog_s, flags);
-                            const uint32_t d = (uint32_t)d64;
-                            up_s = (uint32_t)(d64 >> 32);
+                            const uint32_t d = (uint32_t)ds64;
+                            up_s = (uint32_t)(ds64 >> 32);
                             ok &= (int)((d >> 16) + (d & 0xFFFFu)) == ws.lower;
                         }
                         if (wait_n) {
-                            const unsigned long long d64 = poll_word(prog_n, flags);
-                            up_n = (uint32_t)(d64 >> 32);
-                            ok &= (int)((uint32_t)d64 >> 16) == wn.lower_w;
+                            up_n = (uint32_t)(dn64 >> 32);
+                            ok &= (int)((uint32_t)dn64 >> 16) == wn.lower_w;
                         }
                     }
                     if (wait_s || wait_n) ok = __shfl(ok, 0, W);
                     if (ok) {
                         TURN_CLK(2);
-                        T q0 = pred;  // = the table, unless a lower agent has written my cell in this step
-                        if (sub == 0 && (ws.cols_lower & cell_bit)) q0 = fwd_q0 ? fwd_value<T>(up_s) : rmw_read(c.q + cell);
                         if (fwd_row) {
                             const uint32_t up = __shfl(sep ? up_n : up_s, 0, W);
                             set_col4(row, sub, __ffsll((long long)wr.cols_lower) - 1, fwd_value<T>(up));
                         } else {
                             patch_row4_rmw(row, c.q, n, c.ld, sub, wr.cols_lower);
                         }
+                        // (requested behind the row's columns and used after them: one round trip for all of it)
+                        T q0 = pred;  // = the table, unless a lower agent has written my cell in this step
+                        if (sub == 0 && (ws.cols_lower & cell_bit)) q0 = fwd_q0 ? fwd_value<T>(up_s) : rmw_read(c.q + cell);
                         const T m = row_max_valid<LC>(row, valid, c.L);
                         T u;
                         const T q1 = Td<T>::apply(q0, r, m, term, hyper, c.mode, &u);
@@ -510,7 +517,12 @@ __global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                         phase = 3;
                     }
                 }
-                if (phase == 3) {
+                // A selection (select + env.step + registration: ~2 us with its memory round trip) occupies the whole
+                // wavefront: while an agent of this wavefront still has its UPDATE ahead -- the update the next agent of a
+                // chain is waiting for -- the selections of the others wait, so that its poll is never behind them.  (They
+                // depend on nothing that comes later: the wavefront runs them in one batch after its last update.)
+                const bool update_ahead = __any(phase == 0);
+                if (phase == 3 && !update_ahead) {
                     if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
                     phase = 2;
                 }
