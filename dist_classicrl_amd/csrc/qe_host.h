@@ -296,14 +296,14 @@ Ctx<T> env_ctx(qe_engine* e, qe_env* env) {
 inline unsigned grid_for(int64_t threads, int block) { return (unsigned)((threads + block - 1) / block); }
 
 // Turnstile path (qe_step_turn.h): its workgroups wait for each other inside the launch, so all of them must be
-// resident -- FAST_BLOCK threads each.  How many fit a CU is asked of the runtime for the very kernel that will be
+// resident -- TURN_BLOCK threads each.  How many fit a CU is asked of the runtime for the very kernel that will be
 // launched (hipOccupancyMaxActiveBlocksPerMultiprocessor, turn_occupancy<T, Env> in qe_inst_step.hip); a quarter of the
 // chip is left out of the count, for kernels that share it with the rollout (the collectives of the replica exchange
 // run beside the next chunk).  The progress counts are 16 bits.
 constexpr int TURN_RESERVE_DIV = 4;   // 1 / TURN_RESERVE_DIV of the CUs is not counted on
 constexpr bool TURN_AUTO = true;  // automatic choice for agent counts above the persistent kernel's
 inline bool turn_fits(const qe_engine* e, int64_t N, int blocks_per_cu) {
-    const int64_t blocks = (N * e->L + FAST_BLOCK - 1) / FAST_BLOCK;
+    const int64_t blocks = (N * e->L + TURN_BLOCK - 1) / TURN_BLOCK;
     const int64_t cus = (int64_t)e->num_cus - e->num_cus / TURN_RESERVE_DIV;
     return N <= 60000 && blocks_per_cu > 0 && blocks <= cus * blocks_per_cu && e->ld <= 256;
 }

@@ -15,8 +15,9 @@ void launch_step(qe_engine* e, RolloutSlot& sl, const Ctx<T>& c, const EnvCtx& e
     if (c.turn_next) {  // turnstile path: the whole vector step is this one launch (qe_step_turn.h)
         const int tflags = flags | FLAG_TURN | (e->opt_turn_forward ? 0 : FLAG_TURN_NO_FORWARD) |
                            (e->opt_turn_poll ? 0 : FLAG_TURN_ATOMIC_POLL);
-        if (c.mode == QE_LEARN_VEC) hipLaunchKernelGGL((k_step_turn<T, Env, LC, true>), grid, block, 0, e->stream, c, ev, tflags);
-        else hipLaunchKernelGGL((k_step_turn<T, Env, LC, false>), grid, block, 0, e->stream, c, ev, tflags);
+        const dim3 tgrid(grid_for(c.N * c.L, TURN_BLOCK)), tblock(TURN_BLOCK);
+        if (c.mode == QE_LEARN_VEC) hipLaunchKernelGGL((k_step_turn<T, Env, LC, true>), tgrid, tblock, 0, e->stream, c, ev, tflags);
+        else hipLaunchKernelGGL((k_step_turn<T, Env, LC, false>), tgrid, tblock, 0, e->stream, c, ev, tflags);
         if (sample >= 0) (void)hipEventRecord(sl.sample_ev[2 * sample + 1], e->stream);
         ++sl.launches;
         return;
@@ -167,8 +168,8 @@ int turn_occupancy(const qe_engine* e) {
         constexpr int LC = decltype(lc)::value;
         // (the smaller of the two builds' answers: one capacity for both update modes)
         int nb_iter = 0, nb_vec = 0;
-        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_iter, k_step_turn<T, Env, LC, false>, FAST_BLOCK, 0);
-        if (err == hipSuccess) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_vec, k_step_turn<T, Env, LC, true>, FAST_BLOCK, 0);
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_iter, k_step_turn<T, Env, LC, false>, TURN_BLOCK, 0);
+        if (err == hipSuccess) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_vec, k_step_turn<T, Env, LC, true>, TURN_BLOCK, 0);
         nb = nb_iter < nb_vec ? nb_iter : nb_vec;
     };
     if constexpr (std::is_same<Env, HashEnv>::value) {  // (same choice as launch_step_any)

@@ -257,9 +257,9 @@ __device__ __forceinline__ uint32_t fwd_bits(T v) {
 // VEC: the learn_vec build (its ordering rules are different code; compiled apart so that neither build carries the
 // other's registers: together they cost the learn_iter kernel a quarter of its occupancy and 500 scalar spills).
 template <typename T, class Env, int LC = 0, bool VEC = false>
-__global__ __launch_bounds__(FAST_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, int flags) {
+__global__ __launch_bounds__(TURN_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, int flags) {
     c.mode = VEC ? 1 : 0;
-    const int64_t gl = (int64_t)blockIdx.x * FAST_BLOCK + threadIdx.x;
+    const int64_t gl = (int64_t)blockIdx.x * TURN_BLOCK + threadIdx.x;
     const int64_t i = gl >> c.lshift;
     const int sub = (int)(gl & (c.L - 1));
     const long long t = c.ctrl->t_local + c.turn_t_off;
