@@ -143,6 +143,16 @@ __device__ __forceinline__ void df_pub_write(DfPub<T>* slot, uint32_t stamp, T v
     }
 }
 
+// row = next, by moves that are opaque to the optimiser (see `row_next` in k_rollout_df)
+template <typename T, int NV>
+__device__ __forceinline__ void df_take_row(RowV<T, NV>& row, const RowV<T, NV>& next) {
+#pragma unroll
+    for (int j = 0; j < 4 * NV; ++j) {
+        if constexpr (sizeof(T) == 4) asm volatile("v_mov_b32 %0, %1" : "=v"(row.v[j]) : "v"(next.v[j]));
+        else asm volatile("v_mov_b64 %0, %1" : "=v"(row.v[j]) : "v"(next.v[j]));
+    }
+}
+
 // row.v[col] = v for a run-time column (rare paths: a compare-and-select per column)
 template <typename T, int NV>
 __device__ __forceinline__ void row_set_lane(RowV<T, NV>& row, int col, T v) {
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
     const bool active = FULL ? !helper : (!helper && i < c.N);
     const int ii = i < c.N ? i : 0;
     Pending<T> p;
-    p.n = c.n[ii];
+    p.n = helper ? 0 : c.n[ii];  // (the draw-producing wavefronts gather row 0, one cache line for all lanes: see the end of the step)
     p.aux = c.aux[ii];
     p.s = 0; p.a = 0; p.pred = 0; p.r = 0.0f; p.term = false;
     float acc = c.acc[ii];
@@ -317,7 +327,14 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
         own_prev = own_cur; own_cur = own_next; own_next = own_w;
     };
 
-    RowV<T, NV> row;  // Q[p.n]: gathered before the barrier in front of the step it serves
+    RowV<T, NV> row;  // Q[p.n] of the step being processed
+    // ... as gathered before the barrier in front of that step.  A variable of its own, taken over at the top of the step by
+    // register moves the compiler cannot see through (df_take_row): as ONE loop-carried variable the row is a merge of
+    // "gathered at the end of the step" and "as the step left it", and whenever the register allocator does not give both
+    // the same registers it copies at the end of the step -- behind an `s_waitcnt vmcnt(0)` of its own, which puts the
+    // whole gather latency and the table store's acknowledgement on every step (seen twice in round 3, each time after an
+    // unrelated change of this kernel: 2.44 -> 2.99 us per step at the headline shape).
+    RowV<T, NV> row_next;
     {   // select(0), env.step(0); rows written in step 0; then the bookkeeping of transition 0
         load_row_lane<NV>(row, c.q, p.n);
         if (active) {
@@ -337,7 +354,12 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
         if (helper) produce(1);
         __syncthreads();
         if (active) bookkeeping(0, true);
-        load_row_lane<NV>(row, c.q, p.n);
+        // (the same gather-then-stores sequence as at the end of every step, so that the counted wait at the top of the
+        // loop means the same on both ways into it; the stores go to the dump words)
+        load_row_lane<NV>(row_next, c.q, p.n);
+        asm volatile("" ::: "memory");
+        c.pred[ii] = (T)0;
+        if constexpr (LEAN == 2) reinterpret_cast<DeltaEntry*>(c.pred)[ii] = DeltaEntry{0u, 0.0f};
     }
     __syncthreads();
     DeltaEntry* dl = c.dlog ? c.dlog + c.dlog_base + ii : nullptr;  // this agent's record of step 0
@@ -359,6 +381,7 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
         // the row gather (issued before the barrier) has landed; the table stores issued behind it may still be in flight
         if constexpr (LEAN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        df_take_row<T, NV>(row, row_next);
         // Schedule values one step ahead, as vector loads through a laundered zero offset (see k_rollout_lane) -- issued
         // BEHIND the wait above: in front of it their round trip (a cache miss every eighth step) would sit on the
         // critical path of every step; here they are simply in flight until the end of the step.
@@ -397,39 +420,65 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                 }
             } else {
                 DfPub<T>* const pub_now = lds.pub[par];
+                DfPub<T>* const pub_prev = lds.pub[par ^ 1];
                 const unsigned char* const cols_now = lds.pub_a[t & 3];
-                // ---- writers of my row in the step before: their final values bring the gathered row up to date (the
-                // gather ran beside their stores).  They all published before the barrier.
-                if (__any(active && m128_any(Wst))) {
-                    // (the two lowest side by side -- nearly always all of them; ascending agent index: the highest
-                    // writer of a column wins)
-                    int j0, j1;
-                    const int cnt = m128_two_lowest(active ? Wst : m128_zero(), &j0, &j1);
-                    T v0, v1;
-                    int c0, c1;
-                    (void)df_pub_read(lds.pub[par ^ 1], lds.pub_a[(t + 3) & 3], j0 >= 0 ? j0 : ii, stamp_prev, &v0, &c0);
-                    (void)df_pub_read(lds.pub[par ^ 1], lds.pub_a[(t + 3) & 3], j1 >= 0 ? j1 : ii, stamp_prev, &v1, &c1);
-                    if (cnt >= 1 && cnt <= 2) row_set_lane<T, NV>(row, c0, v0);
-                    if (cnt == 2) row_set_lane<T, NV>(row, c1, v1);
-                    if (cnt > 2) {
-                        M128 w = Wst;
+                const unsigned char* const cols_prev = lds.pub_a[(t + 3) & 3];
+                // ---- who matters to me in this step (masks only; the reference's order is the agent order):
+                //   Wst    writers of my row in the step before: their final values bring the gathered row up to date (the
+                //          gather ran beside their stores; they all published before the barrier)
+                //   S_low  lower-indexed writers of the row I write, N_low of the row my maximum is taken over
+                //   hi     higher-indexed writers of the row I write: the table receives the LAST value of a written cell
+                const M128 S_low = m128_and(Ws, below);
+                const M128 N_low = p.term ? m128_zero() : (self_loop ? S_low : m128_and(Wn, below));
+                dep_u = active && (m128_any(S_low) || m128_any(N_low));
+                M128 hi = active ? m128_andnot(m128_andnot(Ws, below), my_bit) : m128_zero();
+                const bool any_st = __any(active && m128_any(Wst)), any_dep = __any(dep_u), any_hi = __any(m128_any(hi));
+                // the two lowest members of each (nearly always all of them) are looked at side by side ...
+                int j0 = -1, j1 = -1, cnt_st = 0;
+                if (any_st) cnt_st = m128_two_lowest(active ? Wst : m128_zero(), &j0, &j1);
+                int s0 = -1, s1 = -1, ns = 0, n0 = -1, n1 = -1, nn = 0;
+                if (any_dep && dep_u) {
+                    ns = m128_two_lowest(S_low, &s0, &s1);
+                    nn = m128_two_lowest(N_low, &n0, &n1);
+                }
+                int h0 = -1, h1 = -1, nh = 0;
+                if (any_hi) nh = m128_two_lowest(hi, &h0, &h1);
+                // ... and everything about them that sits in LDS is requested in ONE batch (one round trip; as three
+                // sections with their own reads this cost three)
+                T v0 = 0, v1 = 0;
+                int c0 = 0, c1 = 0;
+                if (any_st) {
+                    (void)df_pub_read(pub_prev, cols_prev, j0 >= 0 ? j0 : ii, stamp_prev, &v0, &c0);
+                    (void)df_pub_read(pub_prev, cols_prev, j1 >= 0 ? j1 : ii, stamp_prev, &v1, &c1);
+                }
+                int a_s0 = -1, a_s1 = -1, cn0 = -1, cn1 = -1;  // columns the lower writers write (published with the selection)
+                if (any_dep) {
+                    a_s0 = (int)cols_now[s0 >= 0 ? s0 : ii]; a_s1 = (int)cols_now[s1 >= 0 ? s1 : ii];
+                    cn0 = (int)cols_now[n0 >= 0 ? n0 : ii]; cn1 = (int)cols_now[n1 >= 0 ? n1 : ii];
+                    if (n0 < 0) cn0 = -1;
+                    if (n1 < 0) cn1 = -1;
+                }
+                int a_h0 = -1, a_h1 = -1;
+                if (any_hi) { a_h0 = (int)cols_now[h0 >= 0 ? h0 : ii]; a_h1 = (int)cols_now[h1 >= 0 ? h1 : ii]; }
+                // ---- the gathered row brought up to date (ascending agent index: the highest writer of a column wins)
+                if (any_st) {
+                    if (cnt_st >= 1 && cnt_st <= 2) row_set_lane<T, NV>(row, c0, v0);
+                    if (cnt_st == 2) row_set_lane<T, NV>(row, c1, v1);
+                    if (__any(cnt_st > 2)) {
+                        M128 w = cnt_st > 2 ? Wst : m128_zero();
                         while (m128_any(w)) {
                             const int j = m128_pop_lowest(w);
                             T v;
                             int col;
-                            (void)df_pub_read(lds.pub[par ^ 1], lds.pub_a[(t + 3) & 3], j, stamp_prev, &v, &col);
+                            (void)df_pub_read(pub_prev, cols_prev, j, stamp_prev, &v, &col);
                             row_set_lane<T, NV>(row, col, v);
                         }
                     }
                 }
-                // ---- update of transition t: lower-indexed writers of the row I write / of the row my maximum is taken
-                // over (the reference's order)
-                const M128 S_low = m128_and(Ws, below);
-                const M128 N_low = p.term ? m128_zero() : (self_loop ? S_low : m128_and(Wn, below));
-                dep_u = active && (m128_any(S_low) || m128_any(N_low));
-                if (!__any(dep_u)) {
-                    // nobody here waits for a value: the plain update (the company is higher-indexed, or only matters for
-                    // the selection)
+                // ---- update of transition t
+                if (!any_dep) {
+                    // nobody in this wavefront waits for a value (the company is higher-indexed, or only matters for the
+                    // selection): the plain update
                     if (active) {
                         T m = row_max_lane(masked_row<MASKED>(row, valid));
                         if (row_nan_lane<NV>(masked_row<MASKED>(row, valid))) m = quiet_nan<T>();
@@ -437,20 +486,10 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                         df_pub_write(&pub_now[ii], stamp, q1, p.a);
                     }
                 } else {
-                    // Which lower writers of my row write MY cell (the latest of their values is what I update) -- the
-                    // columns were published with the selection.  Up to two lower writers (nearly always all of them)
-                    // are looked at side by side: their LDS reads are in flight together.
+                    // Which lower writers of my row write MY cell (the latest of their values is what I update)
                     int n_sc = 0;   // lower writers of my cell
                     int hsc = -1;   // ... the highest of them
-                    int n0 = -1, n1 = -1, nn = 0;  // lower writers of the row my maximum is taken over
-                    int cn0 = -1, cn1 = -1;        // ... and the columns they write
                     if (dep_u) {
-                        int s0, s1;
-                        const int ns = m128_two_lowest(S_low, &s0, &s1);
-                        nn = m128_two_lowest(N_low, &n0, &n1);
-                        const int a_s0 = (int)cols_now[s0 >= 0 ? s0 : ii], a_s1 = (int)cols_now[s1 >= 0 ? s1 : ii];
-                        cn0 = n0 >= 0 ? (int)cols_now[n0] : -1;
-                        cn1 = n1 >= 0 ? (int)cols_now[n1] : -1;
                         if (ns <= 2) {
                             const bool m0 = ns >= 1 && a_s0 == p.a, m1 = ns >= 2 && a_s1 == p.a;
                             n_sc = (m0 ? 1 : 0) + (m1 ? 1 : 0);
@@ -474,28 +513,36 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                     bool rest_nan;
                     row_rest_lane<T, NV, M>(masked_row<MASKED>(row, valid), waits && !many ? cn0 : -1, waits && !many ? cn1 : -1,
                                             &rest, &rest_nan);
+                    // Agents that wait for nobody update at once, in straight-line code (the company is higher-indexed, only
+                    // matters for the selection, or forms a chain that is mine to compute); the rounds below are for the others.
                     bool todo = active;
+                    if (active && !waits) {
+                        const T m = rest_nan ? quiet_nan<T>() : rest;
+                        T q = Td<T>::apply(p.pred, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
+                        if (__any(dep_u && local_chain)) {
+                            for (int k = 0; k < (dep_u ? n_sc : 0); ++k) q = Td<T>::apply(q, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
+                        }
+                        q1 = q;
+                        df_pub_write(&pub_now[ii], stamp, q1, p.a);
+                        todo = false;
+                    }
                     int spin = 0;
-                    for (int round = 0; __any(todo) && !timed_out; ++round) {
+                    while (__any(todo) && !timed_out) {
                         if (todo) {
-                            bool ready = true;
-                            T q0 = p.pred, v0 = 0, v1 = 0, m;
-                            if (waits) {
-                                int col;
-                                T qh;
-                                // (three independent reads: one LDS round trip)
-                                const bool ok_h = df_pub_read(pub_now, cols_now, hsc >= 0 ? hsc : ii, stamp, &qh, &col);
-                                const bool ok_0 = df_pub_read(pub_now, cols_now, n0 >= 0 ? n0 : ii, stamp, &v0, &col);
-                                const bool ok_1 = df_pub_read(pub_now, cols_now, n1 >= 0 ? n1 : ii, stamp, &v1, &col);
-                                ready = (hsc < 0 || ok_h) && (n0 < 0 || ok_0) && (n1 < 0 || ok_1);
-                                if (hsc >= 0) q0 = qh;
-                                if (many) {  // the generic form: every lower writer of the row, patched in place
-                                    M128 w = N_low;
-                                    while (m128_any(w)) {
-                                        const int j = m128_pop_lowest(w);
-                                        T v;
-                                        ready &= df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
-                                    }
+                            int col;
+                            T qh, v0r = 0, v1r = 0, m;
+                            // (three independent reads: one LDS round trip)
+                            const bool ok_h = df_pub_read(pub_now, cols_now, hsc >= 0 ? hsc : ii, stamp, &qh, &col);
+                            const bool ok_0 = df_pub_read(pub_now, cols_now, n0 >= 0 ? n0 : ii, stamp, &v0r, &col);
+                            const bool ok_1 = df_pub_read(pub_now, cols_now, n1 >= 0 ? n1 : ii, stamp, &v1r, &col);
+                            bool ready = (hsc < 0 || ok_h) && (n0 < 0 || ok_0) && (n1 < 0 || ok_1);
+                            const T q0 = hsc >= 0 ? qh : p.pred;
+                            if (many) {  // the generic form: every lower writer of the row, patched in place
+                                M128 w = N_low;
+                                while (m128_any(w)) {
+                                    const int j = m128_pop_lowest(w);
+                                    T v;
+                                    ready &= df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
                                 }
                             }
                             if (ready) {
@@ -506,36 +553,29 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                                     while (m128_any(w)) {
                                         const int j = m128_pop_lowest(w);
                                         T v;
-                                        int col;
                                         (void)df_pub_read(pub_now, cols_now, j, stamp, &v, &col);
                                         row_set_lane<T, NV>(row, col, v);
                                     }
                                     m = row_max_np_lane<T, NV>(masked_row<MASKED>(row, valid));
                                 } else {
-                                    m = max_with_patches<T, M>(rest, rest_nan, valid, waits ? nn : 0, cn0, v0, cn1, v1);
+                                    m = max_with_patches<T, M>(rest, rest_nan, valid, nn, cn0, v0r, cn1, v1r);
                                 }
-                                const int reps = (dep_u && local_chain) ? n_sc + 1 : 1;
-                                T q = q0;
-                                for (int k = 0; k < reps; ++k) q = Td<T>::apply(q, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
-                                q1 = q;
+                                q1 = Td<T>::apply(q0, p.r, m, p.term, make_hyper(c, lr_t), 0, &u);
                                 df_pub_write(&pub_now[ii], stamp, q1, p.a);
                                 todo = false;
                             }
                         }
-                        if (round) ++extra_rounds;
+                        ++extra_rounds;
                         if (++spin > DF_SPIN_LIMIT) { timed_out = true; lds.abort_ = 1u; }  // never expected: every wave leaves, error reported
                     }
-                    dep_total += dep_u ? 1ull : 0ull;
                 }
+                dep_total += dep_u ? 1ull : 0ull;
                 // the table receives the LAST value of a written cell: by the highest writer of the cell
-                M128 hi = active ? m128_andnot(m128_andnot(Ws, below), my_bit) : m128_zero();  // higher writers of my row
-                if (__any(m128_any(hi))) {
-                    int h0, h1;
-                    const int nh = m128_two_lowest(hi, &h0, &h1);
-                    const int a_h0 = (int)cols_now[h0 >= 0 ? h0 : ii], a_h1 = (int)cols_now[h1 >= 0 ? h1 : ii];
+                if (any_hi) {
                     if (nh >= 1) is_last &= a_h0 != p.a;
                     if (nh >= 2) is_last &= a_h1 != p.a;
-                    if (nh > 2) {
+                    if (__any(nh > 2)) {
+                        if (nh <= 2) hi = m128_zero();
                         while (m128_any(hi)) {
                             const int j = m128_pop_lowest(hi);
                             is_last &= (int)cols_now[j] != p.a;
@@ -687,14 +727,16 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
         // (~1 us) as well.  Every lane stores (the ones that must not, into a per-agent dump word) so that the wait can
         // name the number of stores behind the gather.
         asm volatile("" ::: "memory");
-        if (!helper) {
-            load_row_lane<NV>(row, c.q, p.n);
-            asm volatile("" ::: "memory");
-            *(is_last ? c.q + cell : c.pred + ii) = q1;
-            if constexpr (LEAN == 2) {
-                DeltaEntry* const rec = (active && dl_ok) ? dl : reinterpret_cast<DeltaEntry*>(c.pred) + ii;
-                *rec = DeltaEntry{(uint32_t)cell, u_t};
-            }
+        // (Every wavefront issues the same sequence, the draw-producing ones included -- they gather an agent's row from the
+        // L1 and store into the dump words: a gather or a store inside a branch makes the state behind it a merge of two
+        // paths, which costs a register copy behind a full wait (see `row_next`) or turns the counted wait at the top of
+        // the step into `vmcnt(0)`, a wait for the table store's acknowledgement.)
+        load_row_lane<NV>(row_next, c.q, p.n);
+        asm volatile("" ::: "memory");
+        *(is_last ? c.q + cell : c.pred + ii) = q1;
+        if constexpr (LEAN == 2) {
+            DeltaEntry* const rec = (active && dl_ok) ? dl : reinterpret_cast<DeltaEntry*>(c.pred) + ii;
+            *rec = DeltaEntry{(uint32_t)cell, u_t};
         }
         asm volatile("" ::: "memory");
         if (active) bookkeeping(t + 1, false);
