@@ -439,10 +439,14 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
     const long long dl_steps = c.dlog ? (c.dlog_cap - c.dlog_base) / c.N : 0;  // steps whose records all fit
     // schedule values are fetched one step ahead of their use (scalar loads whose latency would otherwise
     // sit in front of the update / the selection of every step)
-    double lr_t = c.lr[0];
-    unsigned long long thr_t1 = c.thr[steps > 1 ? 1 : 0];
     int vzero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+    // Schedule values of the coming step, in flight since the step before (see below): taken over behind the explicit wait of
+    // the step that uses them, by moves the compiler cannot see through.  (As plain copies at the END of the step --
+    // `lr_t = lr_next` -- they were a use of loaded values there, and the compiler put an `s_waitcnt vmcnt(0)` behind the step
+    // barrier of EVERY step: a wait for the row gather and the table store, in front of the work that was meant to run under them.)
+    double lr_pend = ((const double*)(uintptr_t)c.lr)[vzero];
+    unsigned long long thr_pend = ((const unsigned long long*)(uintptr_t)c.thr)[(steps > 1 ? 1 : 0) + vzero];
     for (long long t = 0; t < steps; ++t) {
         const bool last = t + 1 == steps;
         const bool dl_ok = t < dl_steps;
@@ -522,8 +526,12 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         // waits for each of them on the spot -- two scalar-memory round trips in front of every step; a vector load is
         // simply in flight until the values are used, at the end of the step).  Issued BEHIND the wait above: in front
         // of it that wait would be a wait for their round trip as well (a cache miss every eighth step).
-        const double lr_next = ((const double*)(uintptr_t)c.lr)[(last ? t : t + 1) + vzero];
-        const unsigned long long thr_next = ((const unsigned long long*)(uintptr_t)c.thr)[(t + 2 < steps ? t + 2 : steps - 1) + vzero];
+        double lr_t;
+        unsigned long long thr_t1;
+        asm volatile("v_mov_b64 %0, %1" : "=v"(lr_t) : "v"(lr_pend));
+        asm volatile("v_mov_b64 %0, %1" : "=v"(thr_t1) : "v"(thr_pend));
+        lr_pend = ((const double*)(uintptr_t)c.lr)[(last ? t : t + 1) + vzero];
+        thr_pend = ((const unsigned long long*)(uintptr_t)c.thr)[(t + 2 < steps ? t + 2 : steps - 1) + vzero];
         const float r_t = p.r;
         const bool term_t = p.term;
         // ---- update of transition t for agents that may go now ----------------------------------
@@ -747,7 +755,6 @@ __global__ __launch_bounds__(HELP ? 4 * CAP : CAP) void k_rollout_lane(InlineSch
         if (active && !QX(2)) stale = bookkeeping(t + 1, true);
         QL_STAMP(1);
         if (!QX(4)) step_barrier<NLOAD>();  // table writes of step t are complete; the sets of steps t+1, t+2 are in
-        lr_t = lr_next; thr_t1 = thr_next;
         if (c.dlog) dl += c.N;
     }
 #ifdef QE_STAMPS
