@@ -281,8 +281,10 @@ __device__ __forceinline__ void turn_push2(const Ctx<T>& c, int64_t i, int64_t r
 template <typename T, class Env, int LC = 0>
 __device__ __forceinline__ void advance_with_draws(const Ctx<T>& c, const EnvCtx& ev, int64_t i, int sub,
                                                    const Row4<T>& row, uint32_t valid, long long t1,
-                                                   int flags, const U4& x, Pending<T>& p) {
-    const bool explore = !(flags & FLAG_DETERMINISTIC) && (unsigned long long)x.x < c.thr[t1];
+                                                   int flags, const U4& x, Pending<T>& p,
+                                                   const unsigned long long* thr_t1 = nullptr) {
+    // (`thr_t1`: the caller has fetched c.thr[t1] already -- the turnstile kernel does, with its first loads)
+    const bool explore = !(flags & FLAG_DETERMINISTIC) && (unsigned long long)x.x < (thr_t1 ? *thr_t1 : c.thr[t1]);
     T picked;
     int act = select_action<LC>(row, valid, sub, c.L, explore, x.y, x.z, &picked, c.nan_select != 0);
     if (act < 0) {

@@ -292,6 +292,27 @@ __global__ __launch_bounds__(TURN_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
             const uint32_t aux0 = c.aux[i];  // (for the selection of step t+1 at the end)
             const Hyper hyper = make_hyper(c, c.lr[t]);
             const uint32_t valid = Env::valid4(ev, i, n, sub);
+            // the draws of the selection of step t+1 depend on (agent, step) only: evaluated here, under the first loads,
+            // instead of ~100 instructions between the last update of the wavefront and its exit
+            const unsigned long long thr_sel = (flags & FLAG_SELECT) ? c.thr[t + 1] : 0ull;  // (exploration threshold of that selection)
+            U4 x_sel;
+            {
+                const unsigned long long step1 = c.step0 + (unsigned long long)(t + 1);
+                x_sel = philox4x32_10(c.agent_offset + (uint32_t)i, (uint32_t)step1, (uint32_t)(step1 >> 32), STREAM_POLICY,
+                                      c.seed_lo, c.seed_hi);
+                asm volatile("" : "+v"(x_sel.x), "+v"(x_sel.y), "+v"(x_sel.z));  // (not sunk to its use)
+            }
+            // selection + env.step + registration of step t+1 from `row` (= Q[n] after every update of step t)
+            auto select_next = [&]() {
+                Pending<T> pn;
+                pn.n = n;
+                pn.aux = aux0;
+                advance_with_draws<T, Env, LC>(c, ev, i, sub, row, valid, t + 1, flags, x_sel, pn, &thr_sel);
+                if (sub == 0) {
+                    c.s[i] = pn.s; c.a[i] = pn.a; c.pred[i] = pn.pred; c.r[i] = pn.r;
+                    c.term[i] = pn.term ? 1 : 0; c.n[i] = pn.n; c.aux[i] = pn.aux;
+                }
+            };
             TurnWalk ws{0, 0, 0, 0, 0ull, 0ull}, wn{0, 0, 0, 0, 0ull, 0ull};
             if (s0.x + n0.x + own.x == 0xFFFFFFFFu) TURN_CLK(7);  // (never true: makes the clock below wait for the loads)
             TURN_CLK(6);
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(TURN_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                     // (selections wait while an agent of this wavefront has its update ahead: see the learn_iter loop below)
                     const bool update_ahead = __any(phase == 0);
                     if (phase == 3 && !update_ahead) {
-                        if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
+                        if (flags & FLAG_SELECT) select_next();
                         phase = 2;
                     }
                     if (phase != 2) __builtin_amdgcn_s_sleep(2);
@@ -523,7 +544,7 @@ __global__ __launch_bounds__(TURN_BLOCK) void k_step_turn(Ctx<T> c, EnvCtx ev, i
                 // depend on nothing that comes later: the wavefront runs them in one batch after its last update.)
                 const bool update_ahead = __any(phase == 0);
                 if (phase == 3 && !update_ahead) {
-                    if (flags & FLAG_SELECT) advance_agent<T, Env, LC>(c, ev, i, sub, n, row, valid, t + 1, flags, aux0);
+                    if (flags & FLAG_SELECT) select_next();
                     phase = 2;
                 }
                 if (phase != 2) __builtin_amdgcn_s_sleep(2);
