@@ -108,11 +108,13 @@ if glob.glob(str(src / "c3_pmc_FETCH_SIZE.log")):  # tools/collect_traffic_c3.sh
         "env_steps_all_launches": env_steps,
         "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
         "l2_hit_rate": hit / max(1.0, hit + miss),
-        "correction": "upper bound: FETCH_SIZE doubled as for the headline kernel although only the row gather uses 16-B-per-lane "
-                      "loads (list heads, links and agent state are 4/8-B loads, counted in full); raw FETCH_SIZE + WRITE_SIZE = "
+        "correction": "upper bound: FETCH_SIZE doubled as for the headline kernel although only the row gather and the row records "
+                      "use 16-B-per-lane loads (agent state: 4/8-B loads, counted in full); raw FETCH_SIZE + WRITE_SIZE = "
                       f"{(fetch + write) * 1024 / env_steps:.0f} B per env-step",
-        "note": "six scattered 8-byte accesses per env-step (two list heads read + exchanged, the cell store, the row) each move a "
-                "whole line: the kernel is bound by the latency of these dependent accesses, not by their bytes",
+        "note": "per env-step the kernel reads two 64-B row records and the 64-B row, performs four memory-side atomics on the "
+                "records (max + add per touched row) and stores two record entries, the cell, seven 4-B words of agent state and an "
+                "8-B log record; every scattered access moves at least a 32-B sector, an atomic one each way.  The kernel is bound "
+                "by the latency of these dependent accesses, not by their bytes",
         "traffic_bytes_all_launches": traffic,
         "traffic_bytes_per_env_step": traffic / env_steps,
         "algorithmic_bytes_per_env_step": line["roofline"]["alg_bytes_per_env_step"],
