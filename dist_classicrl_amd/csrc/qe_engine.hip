@@ -244,15 +244,26 @@ int rollout_begin_impl(qe_engine* e, qe_env* env, RolloutSlot& sl, int64_t steps
             per_cu = turn_occupancy<T, Env>(e);
             if (per_cu <= 0) per_cu = -1;  // (asked once; without an answer the path is not taken)
         }
-        turn = turn_fits(e, env->N, per_cu);
+        turn = turn_fits(e, env->N, per_cu) && !e->turn_no_memory;
+    }
+    // one 64-byte record per (row, step parity): 128 B per table row, allocated when the path is first taken.  No room
+    // for them (a table that fills the device): the step-wise / wide kernels run instead, as for any shape the path
+    // does not take -- same results
+    const size_t recs = (size_t)e->S * 2;
+    const bool fresh = turn && e->turn_rows.cap < recs;
+    if (fresh) {
+        const hipError_t err = e->turn_rows.ensure(recs);
+        if (err == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            e->turn_no_memory = true;
+            turn = false;
+        } else {
+            HIP_TRY(err);
+        }
     }
     if (turn) {
         HIP_TRY(env->turn_next.ensure((size_t)env->N * 4));
-        // one 64-byte record per (row, step parity); they carry a 32-bit step tag and are never cleared per step:
-        // zeroed when allocated and before a tag can repeat
-        const size_t recs = (size_t)e->S * 2;
-        const bool fresh = e->turn_rows.cap < recs;
-        HIP_TRY(e->turn_rows.ensure(recs));
+        // the records carry a 32-bit step tag and are never cleared per step: zeroed when allocated and before a tag can repeat
         if (fresh || ((e->turn_epoch + (unsigned long long)steps + 2ull) >> 31) != (e->turn_epoch >> 31))
             HIP_TRY(hipMemsetAsync(e->turn_rows.p, 0, e->turn_rows.cap * sizeof(TurnRow), e->stream));
         c.turn_next = env->turn_next.p; c.turn_rows = e->turn_rows.p;

@@ -158,6 +158,7 @@ struct qe_engine {
     int opt_path = 0;  // QE_OPT_ROLLOUT_PATH
     unsigned long long turn_epoch = 1;  // turnstile path: record tag of the next call's step 0 (0 = a cleared record)
     DevBuf<TurnRow> turn_rows;          // turnstile path: [S][2] touchers of a row per step parity, allocated on first use
+    bool turn_no_memory = false;        // ... that allocation failed: the path is not taken by this engine
     int turn_blocks_per_cu[4] = {0, 0, 0, 0};  // resident workgroups of k_step_turn per CU, by environment kind (0: not yet asked)
     hipStream_t debug_stream = nullptr;        // qe_debug_occupy_cus
     int opt_graph = 1; // QE_OPT_USE_GRAPH
