@@ -370,6 +370,24 @@ def test_rollout_matches_oracle_seeded(spec, steps, dt, mode, path):
     assert np.array_equal(got["agent_rewards"], want["agent_rewards"])
 
 
+@pytest.mark.parametrize("path", ["turnstile", "turnstile_reread"])
+@pytest.mark.parametrize("mode", ["iter", "vec"])
+@pytest.mark.parametrize("dt", ["f4", "f8"])
+@pytest.mark.parametrize(("agents", "rows"), [(18, 2), (20, 2), (22, 2), (27, 3), (33, 3), (40, 4), (64, 5), (200, 7)])
+def test_turnstile_row_records_around_their_capacity(agents, rows, dt, mode, path):
+    """A row's record holds ten touchers (TURN_ENTRIES, qe_kernels.h); the eleventh onwards goes on the overflow list.
+    Tiny tables put 9 .. 60 touchers on every row -- records exactly full, one over, and mostly on the list -- and the
+    path must still equal the reference's sequential order."""
+    spec = ("hash", agents, rows, 4, False)
+    want = run_oracle_trace(spec, 40, dt, "bench", mode)
+    got = _run_product_trace(spec, 40, dt, "bench", mode, path=path)
+    for k in ("actions", "q", "history", "final_obs", "agent_rewards", "final_sched"):
+        assert np.array_equal(got[k], want[k], equal_nan=(k == "q")), k
+    from dist_classicrl_amd import _lib
+
+    assert _lib.decode_variant(got["stats"]["kernel_variant"])["path"] == "turnstile"
+
+
 @pytest.mark.parametrize("bits", [4, 9, 14])
 @pytest.mark.parametrize("path", ["stepwise", "wide", "wide_listed"])
 @pytest.mark.parametrize(("spec", "steps", "dt", "mode"), [
