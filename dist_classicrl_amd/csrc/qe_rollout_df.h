@@ -129,6 +129,30 @@ __device__ __forceinline__ bool df_pub_read(DfPub<T>* slot, const unsigned char*
         return s == stamp;
     }
 }
+// float32 tables: the record as one word, and its parts.  Several records are REQUESTED first and taken apart afterwards:
+// df_pub_read decodes on the spot, and the compiler keeps two atomic loads in program order -- with the first one's decode
+// between them they cost two LDS round trips instead of one.
+__device__ __forceinline__ unsigned long long df_pub_raw(DfPub<float>* slot, int j) {
+    return __hip_atomic_load(reinterpret_cast<unsigned long long*>(slot + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool df_raw_decode(unsigned long long raw, uint32_t stamp, float* val, int* col) {
+    *val = __uint_as_float((uint32_t)raw);
+    *col = (int)(raw >> 56);
+    return (((uint32_t)(raw >> 32)) & 0xFFFFFFu) == stamp;
+}
+// two records side by side (float32: one round trip)
+template <typename T>
+__device__ __forceinline__ void df_pub_read2(DfPub<T>* slot, const unsigned char* cols, int ja, int jb, uint32_t stamp, T* va,
+                                             int* ca, bool* oka, T* vb, int* cb, bool* okb) {
+    if constexpr (sizeof(T) == 4) {
+        const unsigned long long ra = df_pub_raw(slot, ja), rb = df_pub_raw(slot, jb);
+        *oka = df_raw_decode(ra, stamp, va, ca);
+        *okb = df_raw_decode(rb, stamp, vb, cb);
+    } else {
+        *oka = df_pub_read(slot, cols, ja, stamp, va, ca);
+        *okb = df_pub_read(slot, cols, jb, stamp, vb, cb);
+    }
+}
 template <typename T>
 __device__ __forceinline__ void df_pub_write(DfPub<T>* slot, uint32_t stamp, T val, int col) {
     if constexpr (sizeof(T) == 4) {
@@ -447,9 +471,15 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                 // sections with their own reads this cost three)
                 T v0 = 0, v1 = 0;
                 int c0 = 0, c1 = 0;
+                unsigned long long raw_st0 = 0ull, raw_st1 = 0ull;  // (float32: taken apart behind the other requests)
                 if (any_st) {
-                    (void)df_pub_read(pub_prev, cols_prev, j0 >= 0 ? j0 : ii, stamp_prev, &v0, &c0);
-                    (void)df_pub_read(pub_prev, cols_prev, j1 >= 0 ? j1 : ii, stamp_prev, &v1, &c1);
+                    if constexpr (sizeof(T) == 4) {
+                        raw_st0 = df_pub_raw(pub_prev, j0 >= 0 ? j0 : ii);
+                        raw_st1 = df_pub_raw(pub_prev, j1 >= 0 ? j1 : ii);
+                    } else {
+                        (void)df_pub_read(pub_prev, cols_prev, j0 >= 0 ? j0 : ii, stamp_prev, &v0, &c0);
+                        (void)df_pub_read(pub_prev, cols_prev, j1 >= 0 ? j1 : ii, stamp_prev, &v1, &c1);
+                    }
                 }
                 int a_s0 = -1, a_s1 = -1, cn0 = -1, cn1 = -1;  // columns the lower writers write (published with the selection)
                 if (any_dep) {
@@ -462,6 +492,10 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                 if (any_hi) { a_h0 = (int)cols_now[h0 >= 0 ? h0 : ii]; a_h1 = (int)cols_now[h1 >= 0 ? h1 : ii]; }
                 // ---- the gathered row brought up to date (ascending agent index: the highest writer of a column wins)
                 if (any_st) {
+                    if constexpr (sizeof(T) == 4) {
+                        (void)df_raw_decode(raw_st0, stamp_prev, &v0, &c0);
+                        (void)df_raw_decode(raw_st1, stamp_prev, &v1, &c1);
+                    }
                     if (cnt_st >= 1 && cnt_st <= 2) row_set_lane<T, NV>(row, c0, v0);
                     if (cnt_st == 2) row_set_lane<T, NV>(row, c1, v1);
                     if (__any(cnt_st > 2)) {
@@ -624,8 +658,8 @@ __global__ __launch_bounds__(2 * DF_CAP) void k_rollout_df(InlineSched /*at offs
                         for (int spin = 0; !timed_out; ++spin) {
                             bool ready = true;
                             if (dep_s) {
-                                const bool ok_0 = df_pub_read(pub_now, cols_now, j0 >= 0 ? j0 : ii, stamp, &v0, &c0);
-                                const bool ok_1 = df_pub_read(pub_now, cols_now, j1 >= 0 ? j1 : ii, stamp, &v1, &c1);
+                                bool ok_0, ok_1;
+                                df_pub_read2(pub_now, cols_now, j0 >= 0 ? j0 : ii, j1 >= 0 ? j1 : ii, stamp, &v0, &c0, &ok_0, &v1, &c1, &ok_1);
                                 ready = (j0 < 0 || ok_0) && (j1 < 0 || ok_1);
                                 if (cnt > 2) {
                                     M128 w = others;
