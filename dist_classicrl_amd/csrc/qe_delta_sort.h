@@ -7,19 +7,24 @@
 //
 // The sort: least-significant-digit radix sort, 8 bits per pass, over the bits of the cell index that can differ
 // (ceil(log2(cells)) -- three passes at the headline shape, four at BASELINE config 4).  One pass =
-//   k_dsort_count   : every workgroup (ONE wavefront) counts the digits of its tile of DSORT_TILE records
+//   k_dsort_count   : every workgroup (four wavefronts) counts the digits of its tile of DSORT_TILE records, sixteen
+//                     loads per lane in flight
 //   k_dsort_scan_*  : exclusive scan of the counts in (digit, tile) order = where each tile's records of a digit go
-//   k_dsort_scatter : the same wavefront walks its tile 64 records at a time in input order; lanes holding the same
-//                     digit find each other with eight ballots (one per digit bit), the lowest of them advances the
-//                     digit's cursor in LDS, every lane takes cursor + its rank among its peers: stable.  The tile is
-//                     sorted into LDS first and leaves in runs of one digit (scattered 8-byte stores sustain ~35 GB/s).
+//   k_dsort_scatter : each of the four wavefronts holds a quarter of the tile in registers (sixteen records per lane,
+//                     requested together), counts its digits, and -- after a scan over (digit, quarter) -- walks its quarter
+//                     64 records at a time in input order: lanes holding the same digit find each other with eight ballots
+//                     (one per digit bit), the lowest of them advances the digit's cursor in LDS, every lane takes cursor +
+//                     its rank among its peers: stable.  The tile is sorted into LDS first and leaves in runs of one digit
+//                     (scattered 8-byte stores sustain ~35 GB/s).
+//                     (Round 3's first version walked the whole tile with ONE wavefront and one load in flight: 64 dependent
+//                     memory round trips per tile, 103 us per pass at config 4 = 0.9 TB/s; and read the tile three times.)
 // The first pass reads the gathered buffer directly, skipping this rank's own segment (no concatenation pass).
 #pragma once
 #include "qe_kernels.h"
 
 namespace qe {
 
-constexpr int DSORT_TILE = 4096;   // records per workgroup (one wavefront walks them in order; staged in 32 KB of LDS)
+constexpr int DSORT_TILE = 4096;   // records per workgroup (staged in 32 KB of LDS)
 constexpr int DSORT_BINS = 256;
 
 // record g (0 <= g < (world - 1) * count) of "everybody else's logs, rank-major": where it sits in the gathered buffer
@@ -30,29 +35,28 @@ __device__ __forceinline__ long long dsort_src(long long g, long long count, lon
 }
 
 // `first`: read through dsort_src from the gathered buffer; otherwise `in` is a dense array of `n` records
-__global__ __launch_bounds__(64) void k_dsort_count(const DeltaEntry* in, long long n, int shift, int first, long long count,
-                                                    long long capacity, int rank, unsigned* hist, int n_tiles) {
+constexpr int DSORT_BLOCK = 256;                          // threads per tile
+constexpr int DSORT_PER_LANE = DSORT_TILE / DSORT_BLOCK;  // records per lane (16)
+
+__global__ __launch_bounds__(DSORT_BLOCK) void k_dsort_count(const DeltaEntry* in, long long n, int shift, int first, long long count,
+                                                             long long capacity, int rank, unsigned* hist, int n_tiles) {
     __shared__ unsigned bins[DSORT_BINS];
-    const int lane = threadIdx.x, tile = blockIdx.x;
-    for (int k = lane; k < DSORT_BINS; k += 64) bins[k] = 0u;
-    if (tile == 0 && lane == 0) hist[(long long)DSORT_BINS * (n_tiles + 1)] = 0u;  // the pass's "one digit only" flag
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    bins[tid] = 0u;
+    if (tile == 0 && tid == 0) hist[(long long)DSORT_BINS * (n_tiles + 1)] = 0u;  // the pass's "one digit only" flag
     __syncthreads();
     const long long base = (long long)tile * DSORT_TILE;
-    for (int off = lane; off < DSORT_TILE; off += 256) {  // (four independent loads in flight)
-        uint32_t cell[4];
-        bool live[4];
+    uint32_t cell[DSORT_PER_LANE];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long g = base + off + 64 * k;
-            live[k] = g < n;
-            cell[k] = live[k] ? in[first ? dsort_src(g, count, capacity, rank) : g].cell : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (live[k]) atomicAdd(&bins[(cell[k] >> shift) & 0xFFu], 1u);
+    for (int k = 0; k < DSORT_PER_LANE; ++k) {  // (all of a lane's loads in flight together)
+        const long long g = base + tid + DSORT_BLOCK * k;
+        cell[k] = g < n ? in[first ? dsort_src(g, count, capacity, rank) : g].cell : 0xFFFFFFFFu;
     }
+#pragma unroll
+    for (int k = 0; k < DSORT_PER_LANE; ++k)
+        if (base + tid + DSORT_BLOCK * k < n) atomicAdd(&bins[(cell[k] >> shift) & 0xFFu], 1u);
     __syncthreads();
-    for (int k = lane; k < DSORT_BINS; k += 64) hist[(long long)k * n_tiles + tile] = bins[k];
+    hist[(long long)tid * n_tiles + tile] = bins[tid];
 }
 
 // Where the records of (digit, tile) go = digit_base[digit] + the digit's records in earlier tiles.
@@ -89,87 +93,82 @@ __global__ __launch_bounds__(256) void k_dsort_scan_digits(unsigned* totals, lon
     totals[tid] = (unsigned)excl;
 }
 
-__global__ __launch_bounds__(64) void k_dsort_scatter(const DeltaEntry* in, DeltaEntry* out, long long n, int shift, int first,
-                                                      long long count, long long capacity, int rank, const unsigned* offs,
-                                                      const unsigned* digit_base, int n_tiles, const unsigned* flag) {
-    __shared__ DeltaEntry stage[DSORT_TILE];   // the tile, sorted by digit (stable), before it goes out in runs
-    __shared__ unsigned cursor[DSORT_BINS], lstart[DSORT_BINS], gbase[DSORT_BINS];
-    const int lane = threadIdx.x, tile = blockIdx.x;
+__global__ __launch_bounds__(DSORT_BLOCK) void k_dsort_scatter(const DeltaEntry* in, DeltaEntry* out, long long n, int shift,
+                                                               int first, long long count, long long capacity, int rank,
+                                                               const unsigned* offs, const unsigned* digit_base, int n_tiles,
+                                                               const unsigned* flag) {
+    constexpr int NW = DSORT_BLOCK / 64;            // wavefronts = quarters of the tile
+    constexpr int QUARTER = DSORT_TILE / NW;        // records per wavefront, in input order
+    constexpr int BATCHES = QUARTER / 64;           // ... walked 64 at a time
+    __shared__ DeltaEntry stage[DSORT_TILE];        // the tile, sorted by digit (stable), before it goes out in runs
+    __shared__ unsigned cursor[NW][DSORT_BINS];     // per quarter: digit counts, then the next free place of the digit's run
+    __shared__ unsigned lstart[DSORT_BINS], gbase[DSORT_BINS];
+    __shared__ int scan[18];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tile = blockIdx.x;
     const bool keep_order = flag[0] != 0u;  // a single digit holds every record: a plain ordered copy
     const long long base = (long long)tile * DSORT_TILE;
     const int tile_n = (int)(n - base < DSORT_TILE ? n - base : DSORT_TILE);
-    auto fetch = [&](int off) {
-        const long long g = base + off + lane;
-        DeltaEntry e{0u, 0.0f};
-        if (off + lane < tile_n) e = in[first ? dsort_src(g, count, capacity, rank) : g];
-        return e;
-    };
+    // my wavefront's quarter, sixteen records per lane: record b * 64 + lane of the quarter in e[b]
+    DeltaEntry e[BATCHES];
+#pragma unroll
+    for (int b = 0; b < BATCHES; ++b) {
+        const int idx = wave * QUARTER + b * 64 + lane;
+        e[b] = DeltaEntry{0u, 0.0f};
+        if (idx < tile_n) e[b] = in[first ? dsort_src(base + idx, count, capacity, rank) : base + idx];
+    }
     if (keep_order) {
-        for (int off = 0; off < tile_n; off += 64)
-            if (off + lane < tile_n) out[base + off + lane] = fetch(off);
+#pragma unroll
+        for (int b = 0; b < BATCHES; ++b) {
+            const int idx = wave * QUARTER + b * 64 + lane;
+            if (idx < tile_n) out[base + idx] = e[b];
+        }
         return;
     }
-    // digit counts of this tile (as k_dsort_count), their exclusive scan = where each digit's run starts in `stage`
-    for (int k = lane; k < DSORT_BINS; k += 64) cursor[k] = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) cursor[w][tid] = 0u;
     __syncthreads();
-    for (int off = 0; off < tile_n; off += 256) {
-        DeltaEntry e[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = fetch(off + 64 * k);
+    for (int b = 0; b < BATCHES; ++b)
+        if (wave * QUARTER + b * 64 + lane < tile_n) atomicAdd(&cursor[wave][(e[b].cell >> shift) & 0xFFu], 1u);
+    __syncthreads();
+    {   // thread d: where digit d's run starts in `stage`, where each quarter's share of it starts, where the run goes
+        unsigned v[NW], sum = 0u;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (off + 64 * k + lane < tile_n) atomicAdd(&cursor[(e[k].cell >> shift) & 0xFFu], 1u);
+        for (int w = 0; w < NW; ++w) { v[w] = cursor[w][tid]; sum += v[w]; }
+        int total;
+        unsigned run = (unsigned)block_excl_scan((int)sum, &total, scan);
+        lstart[tid] = run;
+        gbase[tid] = digit_base[tid] + offs[(long long)tid * n_tiles + tile];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { cursor[w][tid] = run; run += v[w]; }
     }
     __syncthreads();
-    {
-        unsigned v[4], sum = 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = cursor[4 * lane + k]; sum += v[k]; }
-        unsigned incl = sum;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        unsigned run = incl - sum;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lstart[4 * lane + k] = run;
-            cursor[4 * lane + k] = run;
-            gbase[4 * lane + k] = digit_base[4 * lane + k] + offs[(long long)(4 * lane + k) * n_tiles + tile];
-            run += v[k];
-        }
-    }
-    __syncthreads();
-    // the tile in input order, 64 records at a time: lanes holding the same digit find each other with eight ballots,
+    // my quarter in input order, 64 records at a time: lanes holding the same digit find each other with eight ballots,
     // take consecutive places behind the digit's cursor in rank order, the lowest of them advances the cursor
-    DeltaEntry e_next = fetch(0);
-    for (int off = 0; off < tile_n; off += 64) {
-        const bool live = off + lane < tile_n;
-        const DeltaEntry e = e_next;
-        e_next = fetch(off + 64);  // (in flight while this batch is ranked)
-        const unsigned digit = (e.cell >> shift) & 0xFFu;
+#pragma unroll
+    for (int b = 0; b < BATCHES; ++b) {
+        const bool live = wave * QUARTER + b * 64 + lane < tile_n;
+        const unsigned digit = (e[b].cell >> shift) & 0xFFu;
         unsigned long long peers = __ballot(live);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const unsigned long long has = __ballot((digit >> b) & 1u);
-            peers &= ((digit >> b) & 1u) ? has : ~has;
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long has = __ballot((digit >> k) & 1u);
+            peers &= ((digit >> k) & 1u) ? has : ~has;
         }
         const unsigned rank_in = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
         unsigned pos = 0u;
-        if (live) pos = cursor[digit] + rank_in;  // (read before the leader advances the cursor: LDS in order per wave)
+        if (live) pos = cursor[wave][digit] + rank_in;  // (read before the leader advances the cursor: LDS in order per wave)
         __builtin_amdgcn_wave_barrier();
-        if (live && rank_in == 0u) cursor[digit] += (unsigned)__popcll(peers);
+        if (live && rank_in == 0u) cursor[wave][digit] += (unsigned)__popcll(peers);
         __builtin_amdgcn_wave_barrier();
-        if (live) stage[pos] = e;
+        if (live) stage[pos] = e[b];
     }
     __syncthreads();
     // out in runs: consecutive lanes hold consecutive records of (mostly) one digit -> consecutive addresses
-    for (int idx = lane; idx < tile_n; idx += 64) {
-        const DeltaEntry e = stage[idx];
-        const unsigned digit = (e.cell >> shift) & 0xFFu;
-        out[gbase[digit] + ((unsigned)idx - lstart[digit])] = e;
+    for (int idx = tid; idx < tile_n; idx += DSORT_BLOCK) {
+        const DeltaEntry r = stage[idx];
+        const unsigned digit = (r.cell >> shift) & 0xFFu;
+        out[gbase[digit] + ((unsigned)idx - lstart[digit])] = r;
     }
 }
 

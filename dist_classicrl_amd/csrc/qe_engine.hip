@@ -1316,11 +1316,11 @@ int qe_delta_apply_gathered_dev(qe_engine* e, const void* gathered_dev, int64_t 
     for (int p = 0; p < passes; ++p) {
         DeltaEntry* const out = bufs[p & 1];
         const int first = p == 0 ? 1 : 0;
-        hipLaunchKernelGGL(k_dsort_count, dim3(n_tiles), dim3(64), 0, e->stream, in, (long long)n, 8 * p, first, (long long)count,
+        hipLaunchKernelGGL(k_dsort_count, dim3(n_tiles), dim3(DSORT_BLOCK), 0, e->stream, in, (long long)n, 8 * p, first, (long long)count,
                            (long long)capacity, (int)rank, e->ds_hist.p, n_tiles);
         hipLaunchKernelGGL(k_dsort_scan_rows, dim3(DSORT_BINS), dim3(256), 0, e->stream, e->ds_hist.p, n_tiles, totals);
         hipLaunchKernelGGL(k_dsort_scan_digits, dim3(1), dim3(256), 0, e->stream, totals, (long long)n, flag);
-        hipLaunchKernelGGL(k_dsort_scatter, dim3(n_tiles), dim3(64), 0, e->stream, in, out, (long long)n, 8 * p, first,
+        hipLaunchKernelGGL(k_dsort_scatter, dim3(n_tiles), dim3(DSORT_BLOCK), 0, e->stream, in, out, (long long)n, 8 * p, first,
                            (long long)count, (long long)capacity, (int)rank, (const unsigned*)e->ds_hist.p,
                            (const unsigned*)totals, n_tiles, (const unsigned*)flag);
         in = out;
