@@ -70,6 +70,9 @@ def _expected(q0_cells, rec, count, rank):
     (1_000_000, 16, 4, 12800, 12800, 2, 0.01),   # headline shape, 100 steps x 128 agents per rank
     (1_000_000, 16, 8, 409_600, 409_600, 3, 0.02),  # C3 sharded over 8: 100 steps x 4096 agents per rank
     (300, 300, 2, 70000, 65536, 1, 0.0),     # A > 256 (row stride not a power of two), ragged tile boundary
+    (7, 3, 2, 10, 1, 1, 0.0),                # one record
+    (1000, 8, 5, 100, 63, 4, 0.0),           # less than a wavefront's batch per rank, the last rank's view
+    (100_000, 8, 3, 5000, 4097, 0, 0.1),     # one record past a tile, two tiles and two records in all
 ])
 def test_gathered_apply_matches_cpu_simulation_and_the_sorted_path(S, A, world, capacity, count, rank, hot):
     _lib, Algo, _, _, _ = _product()
