@@ -37,6 +37,8 @@ __device__ __forceinline__ long long dsort_src(long long g, long long count, lon
 // `first`: read through dsort_src from the gathered buffer; otherwise `in` is a dense array of `n` records
 constexpr int DSORT_BLOCK = 256;                          // threads per tile
 constexpr int DSORT_PER_LANE = DSORT_TILE / DSORT_BLOCK;  // records per lane (16)
+static_assert(DSORT_BLOCK == DSORT_BINS, "one thread per digit in the count / scan steps of a tile");
+static_assert(DSORT_TILE % DSORT_BLOCK == 0 && (DSORT_TILE / (DSORT_BLOCK / 64)) % 64 == 0, "whole batches per wavefront");
 
 __global__ __launch_bounds__(DSORT_BLOCK) void k_dsort_count(const DeltaEntry* in, long long n, int shift, int first, long long count,
                                                              long long capacity, int rank, unsigned* hist, int n_tiles) {
